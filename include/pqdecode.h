@@ -1,0 +1,160 @@
+/*
+ * pqdecode — MI355X (gfx950) implementation of parquet-go's column-chunk page-decode path.
+ *
+ * C ABI of libpqdecode.so.  Plain pointers and sizes only; this is the surface a cgo shim
+ * binds in place of the reference's per-page Go calls.  The batch unit is one COLUMN CHUNK
+ * (all pages of one leaf column in one row group): the caller walks the page headers
+ * (pqd_scan_pages, or its own thrift reader), hands over the chunk bytes plus one
+ * pqd_page_desc per page, and gets back the typed image of the layout.Table the reference
+ * would have built by calling layout.ReadPage + Page.Decode + Table.Merge for every page
+ * (reader/columnbuffer.go:105-156).
+ *
+ * Error convention: every function returns 0 or a negative PQD_ERR_* code; nothing aborts or
+ * throws across the ABI.  Codes -1..-3 correspond to the reference's io.EOF,
+ * io.ErrUnexpectedEOF and the inputs on which it panics.
+ *
+ * Threading: a pqd_handle is owned by one thread at a time (one per ColumnBufferType /
+ * goroutine in the reference's model, reader/reader.go:306-327); distinct handles are
+ * independent and may be used concurrently.
+ */
+#ifndef PQDECODE_H
+#define PQDECODE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQD_OK 0
+#define PQD_ERR_EOF (-1)                   /* io.EOF */
+#define PQD_ERR_UNEXPECTED_EOF (-2)        /* io.ErrUnexpectedEOF */
+#define PQD_ERR_MALFORMED (-3)             /* input on which the reference panics (short stream, index out of range, ...) */
+#define PQD_ERR_UNSUPPORTED_ENCODING (-4)  /* "Unsupported Encoding method ..." / "Unknown Encoding method", layout/page.go:671,716 */
+#define PQD_ERR_UNSUPPORTED_PAGE_TYPE (-5) /* "Unsupported page type: INDEX_PAGE", layout/page.go:813-814,934 */
+#define PQD_ERR_UNSUPPORTED_TYPE (-6)      /* physical type / encoding combination outside this build */
+#define PQD_ERR_BIT_WIDTH (-7)             /* bit width the kernels do not implement (> 32 hybrid, > 64 delta) */
+#define PQD_ERR_INVALID_ARG (-8)
+#define PQD_ERR_HIP (-9)                   /* a HIP runtime call failed; see pqd_last_error() */
+#define PQD_ERR_NOMEM (-10)
+#define PQD_ERR_NO_DICTIONARY (-11)        /* dictionary-encoded data page without a dictionary page before it */
+#define PQD_ERR_THRIFT (-12)               /* page header could not be parsed */
+
+/* parquet.Type (parquet/parquet.go:28-37) */
+enum { PQD_BOOLEAN = 0, PQD_INT32 = 1, PQD_INT64 = 2, PQD_INT96 = 3, PQD_FLOAT = 4, PQD_DOUBLE = 5,
+       PQD_BYTE_ARRAY = 6, PQD_FIXED_LEN_BYTE_ARRAY = 7 };
+/* parquet.Encoding (parquet/parquet.go:345-355) */
+enum { PQD_ENC_PLAIN = 0, PQD_ENC_PLAIN_DICTIONARY = 2, PQD_ENC_RLE = 3, PQD_ENC_BIT_PACKED = 4,
+       PQD_ENC_DELTA_BINARY_PACKED = 5, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY = 6, PQD_ENC_DELTA_BYTE_ARRAY = 7,
+       PQD_ENC_RLE_DICTIONARY = 8, PQD_ENC_BYTE_STREAM_SPLIT = 9 };
+/* parquet.PageType (parquet/parquet.go:533-538) */
+enum { PQD_DATA_PAGE = 0, PQD_INDEX_PAGE = 1, PQD_DICTIONARY_PAGE = 2, PQD_DATA_PAGE_V2 = 3 };
+
+/* One page of a column chunk, header already parsed (replaces what layout.ReadPage reads from
+ * parquet.PageHeader, layout/page.go:726-833). */
+typedef struct {
+  int32_t page_type;  /* PQD_DATA_PAGE | PQD_DICTIONARY_PAGE | PQD_DATA_PAGE_V2 */
+  int32_t encoding;   /* DataPageHeader.Encoding / DataPageHeaderV2.Encoding / DictionaryPageHeader.Encoding */
+  int32_t num_values; /* header num_values (level slots for data pages, entries for dictionary pages) */
+  int32_t rep_len;    /* v2: repetition_levels_byte_length, else 0 */
+  int32_t def_len;    /* v2: definition_levels_byte_length, else 0 */
+  int32_t reserved;
+  int64_t offset;     /* byte offset of the page body (first byte after the thrift header) in the chunk buffer */
+  int64_t length;     /* compressed_page_size; pages must be UNCOMPRESSED (compress/ is out of scope) */
+} pqd_page_desc;
+
+/* What the reference takes from schema.SchemaHandler and parquet.ColumnMetaData for one leaf
+ * (layout/page.go:797-805, :821-822, :897-900). */
+typedef struct {
+  int32_t physical_type; /* PQD_* type */
+  int32_t type_length;   /* FIXED_LEN_BYTE_ARRAY length, else 0 */
+  int32_t max_def;       /* SchemaHandler.MaxDefinitionLevel(path) */
+  int32_t max_rep;       /* SchemaHandler.MaxRepetitionLevel(path) */
+} pqd_column_desc;
+
+/* Totals of one decoded chunk (what ReadPage returns per page, summed: numValues, numRows). */
+typedef struct {
+  int64_t num_slots;   /* level slots = sum of data-page num_values = len(Table.Values) */
+  int64_t num_values;  /* non-null values */
+  int64_t num_nulls;   /* slots with def != max_def (layout/page.go:883-888) */
+  int64_t num_rows;    /* slots with rep == 0 (layout/page.go:925-927) */
+  int64_t bytes_len;   /* BYTE_ARRAY: total payload bytes, else 0 */
+  int32_t elem_size;   /* bytes per element of `values` (0 for BYTE_ARRAY) */
+  int32_t status;      /* PQD_OK or the first failing page's error */
+  int32_t bad_page;    /* index of that page, else -1 */
+  int32_t has_levels;  /* bit 0: def array present, bit 1: rep array present (absent = all zero) */
+} pqd_chunk_result;
+
+/* Device-resident result buffers; owned by the handle, valid until its next decode call.
+ * values: num_slots elements of elem_size bytes, null slots zero (BOOLEAN one byte 0/1, INT96 12 bytes).
+ * BYTE_ARRAY: offsets[num_slots+1] (int64) into bytes; null slots have zero length.
+ * def_levels / rep_levels: int32[num_slots], NULL when the column's max level is 0. */
+typedef struct {
+  void *values;
+  int32_t *def_levels;
+  int32_t *rep_levels;
+  int64_t *offsets;
+  uint8_t *bytes;
+} pqd_device_result;
+
+/* Per-kernel device time of the last decode call, when profiling is on. */
+typedef struct {
+  char name[48];
+  float ms;
+  int32_t launches;
+} pqd_kernel_time;
+
+typedef struct pqd_handle pqd_handle;
+
+const char *pqd_version(void);
+const char *pqd_last_error(void);      /* thread-local text of the last PQD_ERR_HIP / INVALID_ARG */
+const char *pqd_strerror(int code);
+int pqd_device_count(int *n_out);
+
+/* One handle = one HIP stream + grow-only device workspaces on `device`.
+ * stream == NULL: the handle creates its own stream; otherwise it enqueues on the given hipStream_t. */
+int pqd_handle_create(int device, void *stream, pqd_handle **out);
+int pqd_handle_destroy(pqd_handle *h);
+int pqd_set_profiling(pqd_handle *h, int on);
+
+/* Host-side page walk over the bytes of one column chunk: parses each thrift compact PageHeader and
+ * fills one descriptor per page until total_values level slots are covered (the loop condition of
+ * ColumnBufferType.ReadPage, reader/columnbuffer.go:106) or the buffer ends.
+ * Replaces layout.ReadPageHeader, layout/page.go:625-630. */
+int pqd_scan_pages(const uint8_t *chunk, size_t len, int64_t total_values, pqd_page_desc *out, int32_t cap,
+                   int32_t *n_out);
+
+/* Decode one column chunk whose bytes are in HOST memory: copies them through pinned staging to the
+ * device, then runs the same kernels as pqd_decode_chunk_device.  Asynchronous on the handle's stream
+ * apart from the staging copy; pqd_wait() completes it.
+ * Replaces the per-page loop layout.ReadPage (layout/page.go:721) + Page.Decode (:139) + Table.Merge. */
+int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages,
+                     int32_t n_pages, const pqd_column_desc *col);
+
+/* Same, chunk bytes already in device memory.  d_chunk must be 16-byte aligned and readable up to
+ * len rounded up to a multiple of 16 (any hipMalloc / torch allocation is). */
+int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages,
+                            int32_t n_pages, const pqd_column_desc *col);
+
+/* Wait for the handle's stream and collect status and totals. */
+int pqd_wait(pqd_handle *h, pqd_chunk_result *res);
+
+/* Device pointers of the last decoded chunk (after pqd_wait). */
+int pqd_result_device(pqd_handle *h, pqd_device_result *out);
+
+/* Copy the last result to host buffers (any pointer may be NULL to skip it).  def/rep are written as
+ * zeros when the column has no such levels, as the reference's Table holds them. */
+int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_levels, int64_t *offsets,
+                 uint8_t *bytes);
+
+/* Per-page (numNulls, numRows, numValues) of the last decoded chunk, 3 x int64 per page in page order
+ * (dictionary pages report zeros). */
+int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages);
+
+/* Per-kernel timings of the last decode call (pqd_set_profiling(h, 1) first). */
+int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,257 @@
+// PLAIN encoding on gfx950: fixed-width reinterpretation copies, BOOLEAN bit unpack, dictionary page
+// materialisation and the null scatter (dense values -> one slot per level entry).
+//
+// Reference behaviour reproduced here: encoding/encodingread.go:13-125, encoding/binaryread.go:10-92
+// (PLAIN), layout/page.go:792-811 (dictionary page), :905-931 (value scatter).
+#include <hip/hip_runtime.h>
+#include "pqd_kernels.h"
+
+namespace pqd {
+
+struct V16Unaligned { uint32_t v[4]; } __attribute__((packed));
+
+__device__ __forceinline__ void set_status1(int32_t *p, int code) { atomicCAS(p, 0, code); }
+
+// Status of reading n elements of esz bytes from a section of `len` bytes.
+// INT32/INT64/FLOAT/DOUBLE use io.ReadFull (binaryread.go:12-18); INT96 / FIXED_LEN_BYTE_ARRAY read each
+// element leniently and fail only when an element starts at the end (encodingread.go:76, :119).
+__device__ __forceinline__ int plain_fixed_status(int ptype, int64_t len, int64_t n, int esz) {
+  if (n <= 0) return PQD_OK;
+  const int64_t need = n * (int64_t)esz;
+  if (ptype == PQD_INT96 || ptype == PQD_FIXED_LEN_BYTE_ARRAY) {
+    if (len <= (n - 1) * (int64_t)esz) return PQD_ERR_EOF;  // also esz == 0 at the end of the section
+    return PQD_OK;
+  }
+  if (need == 0) return PQD_OK;
+  if (len <= 0) return PQD_ERR_EOF;
+  if (len < need) return PQD_ERR_UNEXPECTED_EOF;
+  return PQD_OK;
+}
+
+// Copies `n` bytes src -> dst (both arbitrarily aligned), bytes at or beyond `src_avail` read as zero.
+// Called by a whole block; `first` is the block's first byte.
+__device__ __forceinline__ void block_copy_tile(const uint8_t *src, int64_t src_avail, uint8_t *dst, int64_t n,
+                                                int64_t first, int tile_bytes) {
+  const int tid = threadIdx.x;
+  for (int o = tid * 16; o < tile_bytes; o += 256 * 16) {
+    const int64_t b = first + o;
+    if (b >= n) break;
+    if (b + 16 <= n && b + 16 <= src_avail) {
+      *reinterpret_cast<V16Unaligned *>(dst + b) = *reinterpret_cast<const V16Unaligned *>(src + b);
+    } else {
+      for (int k = 0; k < 16 && b + k < n; k++) dst[b + k] = (b + k < src_avail) ? src[b + k] : (uint8_t)0;
+    }
+  }
+}
+
+// ---- dictionary page, fixed-width types: PLAIN values copied to an aligned table ----
+__global__ __launch_bounds__(256) void k_dict_plain_fixed(ChunkCtx c, int dict_page, uint8_t *dict_out) {
+  const PageIn pi = c.pages[dict_page];
+  const int64_t n = pi.num_values;
+  const int64_t bytes = n * (int64_t)c.elem_size;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int st = n < 0 ? PQD_ERR_MALFORMED : plain_fixed_status(c.physical_type, pi.body_len, n, c.elem_size);
+    if (st) set_status1(&c.state[dict_page].status, st);
+  }
+  for (int64_t first = (int64_t)blockIdx.x * kPlainTile; first < bytes; first += (int64_t)gridDim.x * kPlainTile)
+    block_copy_tile(c.in + pi.body_off, pi.body_len, dict_out, bytes, first, kPlainTile);
+}
+
+// ---- data pages, PLAIN fixed-width values ----
+struct PlainArgs {
+  ChunkCtx c;
+  const int32_t *tile_prefix;  // per data page, nd + 1 entries
+  int n_tiles;
+  uint8_t *values_out;
+};
+
+__global__ __launch_bounds__(256) void k_plain_fixed(PlainArgs a) {
+  const ChunkCtx &c = a.c;
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    int lo = 0, hi = c.nd;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (a.tile_prefix[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const int k = tile - a.tile_prefix[lo];
+    const Stream *vs = &c.streams[2 * c.nd + lo];
+    const int p = vs->page;
+    PageState *ps = &c.state[p];
+    if (ps->status != 0) continue;
+    const int64_t cnt = ps->cnt;
+    const int64_t bytes = cnt * (int64_t)c.elem_size;
+    if (k == 0 && threadIdx.x == 0) {
+      int st = plain_fixed_status(c.physical_type, ps->val_len, cnt, c.elem_size);
+      if (st) set_status1(&ps->status, st);
+    }
+    const int64_t first = (int64_t)k * kPlainTile;
+    if (first >= bytes) continue;
+    block_copy_tile(c.in + ps->val_off, ps->val_len, a.values_out + ps->dense_base * (int64_t)c.elem_size, bytes, first,
+                    kPlainTile);
+  }
+}
+
+// ---- data pages, PLAIN BOOLEAN: bit k of byte k/8, LSB first -> one byte per value ----
+// The reference routes this through ReadBitPacked with header cnt<<1 (encodingread.go:42): an empty
+// section is io.EOF, a short one is zero filled.
+__global__ __launch_bounds__(256) void k_plain_boolean(PlainArgs a) {
+  const ChunkCtx &c = a.c;
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    int lo = 0, hi = c.nd;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (a.tile_prefix[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const int k = tile - a.tile_prefix[lo];
+    const Stream *vs = &c.streams[2 * c.nd + lo];
+    PageState *ps = &c.state[vs->page];
+    if (ps->status != 0) continue;
+    const int64_t cnt = ps->cnt;
+    if (cnt <= 0) continue;
+    if (ps->val_len <= 0) {
+      if (k == 0 && threadIdx.x == 0) set_status1(&ps->status, PQD_ERR_EOF);
+      continue;
+    }
+    const uint8_t *src = c.in + ps->val_off;
+    uint8_t *dst = a.values_out + ps->dense_base;
+    const int64_t first = (int64_t)k * kPlainTile;  // values
+    for (int o = threadIdx.x * 16; o < kPlainTile; o += 256 * 16) {
+      const int64_t v = first + o;
+      if (v >= cnt) break;
+      const int64_t byte = v >> 3;
+      uint32_t bits = 0;
+      if (byte < ps->val_len) bits |= src[byte];
+      if (byte + 1 < ps->val_len) bits |= (uint32_t)src[byte + 1] << 8;
+      uint32_t o4[4];
+      for (int q = 0; q < 4; q++) {
+        uint32_t b4 = (bits >> (4 * q)) & 0xFu;
+        o4[q] = (b4 & 1u) | ((b4 & 2u) << 7) | ((b4 & 4u) << 14) | ((b4 & 8u) << 21);
+      }
+      if (v + 16 <= cnt) {
+        V16Unaligned x = {{o4[0], o4[1], o4[2], o4[3]}};
+        *reinterpret_cast<V16Unaligned *>(dst + v) = x;
+      } else {
+        for (int j = 0; v + j < cnt; j++) dst[v + j] = (uint8_t)((bits >> j) & 1u);
+      }
+    }
+  }
+}
+
+// ---- null scatter: out[i] = def[i] == max_def ? dense[rank(i)] : 0 ----
+constexpr int kScatterTile = 4096;
+
+__global__ __launch_bounds__(256) void k_scatter_count(const int32_t *def, int64_t n, int max_def, int64_t *partial) {
+  __shared__ int s_cnt[4];
+  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
+  int c = 0;
+  for (int i = threadIdx.x; i < kScatterTile; i += 256) {
+    int64_t s = base + i;
+    if (s < n) c += def[s] == max_def;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (int64_t)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive scan of the per-tile counts, one block
+__global__ __launch_bounds__(1024) void k_scatter_scan(int64_t *partial, int n_tiles) {
+  __shared__ int64_t s[1024];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    const int64_t x = t < n_tiles ? partial[t] : 0;
+    s[threadIdx.x] = x;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int64_t y = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (t < n_tiles) partial[t] = carry + s[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+}
+
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_scatter_apply(const int32_t *def, int64_t n, int max_def, const int64_t *partial,
+                                                       const uint8_t *dense, uint8_t *out, int esz) {
+  __shared__ int s_wave[4];
+  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // thread handles 16 consecutive slots
+  const int64_t s0 = base + (int64_t)tid * 16;
+  uint32_t valid = 0;
+  for (int j = 0; j < 16; j++)
+    if (s0 + j < n && def[s0 + j] == max_def) valid |= 1u << j;
+  int c = __builtin_popcount(valid);
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int q = 0; q < wv; q++) wbase += s_wave[q];
+  int64_t rank = partial[blockIdx.x] + wbase + incl - c;
+  for (int j = 0; j < 16; j++) {
+    const int64_t s = s0 + j;
+    if (s >= n) break;
+    const bool v = (valid >> j) & 1u;
+    if (ESZ == 4) {
+      reinterpret_cast<uint32_t *>(out)[s] = v ? reinterpret_cast<const uint32_t *>(dense)[rank] : 0u;
+    } else if (ESZ == 8) {
+      reinterpret_cast<uint64_t *>(out)[s] = v ? reinterpret_cast<const uint64_t *>(dense)[rank] : 0ull;
+    } else {
+      for (int b = 0; b < esz; b++) out[s * esz + b] = v ? dense[rank * esz + b] : (uint8_t)0;
+    }
+    rank += v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_dict_plain_fixed, dim3(16), dim3(256), 0, stream, c, dict_page, dict_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+                              hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  PlainArgs a{c, tile_prefix, n_tiles, values_out};
+  int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
+  hipLaunchKernelGGL(k_plain_fixed, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_plain_boolean(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+                                hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  PlainArgs a{c, tile_prefix, n_tiles, values_out};
+  int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
+  hipLaunchKernelGGL(k_plain_boolean, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, const uint8_t *dense, uint8_t *out,
+                                int64_t n_slots, int64_t *scratch, hipStream_t stream) {
+  if (n_slots <= 0) return hipSuccess;
+  const int n_tiles = (int)((n_slots + kScatterTile - 1) / kScatterTile);
+  hipLaunchKernelGGL(k_scatter_count, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch);
+  hipLaunchKernelGGL(k_scatter_scan, dim3(1), dim3(1024), 0, stream, scratch, n_tiles);
+  if (c.elem_size == 4)
+    hipLaunchKernelGGL(k_scatter_apply<4>, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch, dense, out, 4);
+  else if (c.elem_size == 8)
+    hipLaunchKernelGGL(k_scatter_apply<8>, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch, dense, out, 8);
+  else
+    hipLaunchKernelGGL(k_scatter_apply<1>, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch, dense, out, c.elem_size);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -1,0 +1,562 @@
+// C ABI of libpqdecode.so: handles, workspaces and the per-chunk kernel sequence.
+//
+// Mirrors, per column chunk, the loop ColumnBufferType.ReadPage runs per page
+// (reader/columnbuffer.go:105-156): layout.ReadPage (layout/page.go:721-937) -> Page.Decode (:139-164)
+// -> Table.Merge (layout/table.go:52-71).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "pqd_kernels.h"
+
+using namespace pqd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return PQD_ERR_HIP;
+}
+int fail_arg(const char *what) {
+  g_last_error = what;
+  return PQD_ERR_INVALID_ARG;
+}
+
+#define HIP_TRY(expr)                                \
+  do {                                               \
+    hipError_t _e = (expr);                          \
+    if (_e != hipSuccess) return fail_hip(_e, #expr); \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return PQD_OK;
+    size_t want = std::max(n, cap + cap / 2);
+    want = (want + 255) / 256 * 256;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return fail_hip(e, "hipFree"); }
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e == hipErrorOutOfMemory ? PQD_ERR_NOMEM : fail_hip(e, "hipMalloc"); }
+    cap = want;
+    return PQD_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return PQD_OK;
+    size_t want = std::max(n, cap + cap / 2);
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipHostMalloc"); }
+    cap = want;
+    return PQD_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct KernelEvent {
+  const char *name;
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct pqd_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  bool profiling = false;
+
+  DevBuf in, meta, runs, tile_run, dict, values, dense, def, rep, offsets, bytes, scratch, small;
+  PinnedBuf stage_in, stage_meta, host_small;
+
+  // description of the last decode call
+  std::vector<PageIn> h_pages;
+  pqd_column_desc col{};
+  int n_pages = 0, nd = 0;
+  int64_t total_slots = 0;
+  int elem_size = 0;
+  bool busy = false;
+  bool have_result = false;
+  pqd_chunk_result result{};
+  ChunkCtx ctx{};
+
+  std::vector<KernelEvent> events;   // pool
+  size_t n_events = 0;               // used by the last call
+};
+
+namespace {
+
+struct Guard {
+  int prev = -1;
+  explicit Guard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~Guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct Prof {
+  pqd_handle *h;
+  KernelEvent *ev = nullptr;
+  Prof(pqd_handle *hh, const char *name) : h(hh) {
+    if (!h->profiling) return;
+    if (h->n_events == h->events.size()) {
+      KernelEvent e{name, nullptr, nullptr};
+      if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess) return;
+      h->events.push_back(e);
+    }
+    ev = &h->events[h->n_events++];
+    ev->name = name;
+    (void)hipEventRecord(ev->start, h->stream);
+  }
+  ~Prof() { if (ev) (void)hipEventRecord(ev->stop, h->stream); }
+};
+
+int elem_size_of(const pqd_column_desc &c) {
+  switch (c.physical_type) {
+    case PQD_BOOLEAN: return 1;
+    case PQD_INT32: case PQD_FLOAT: return 4;
+    case PQD_INT64: case PQD_DOUBLE: return 8;
+    case PQD_INT96: return 12;
+    case PQD_FIXED_LEN_BYTE_ARRAY: return c.type_length;
+    default: return 0;
+  }
+}
+
+bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY; }
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// The whole per-chunk sequence; d_in already holds the chunk bytes.
+int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_page_desc *pages, int32_t n_pages,
+                     const pqd_column_desc *col) {
+  h->have_result = false;
+  h->n_events = 0;
+  h->col = *col;
+  h->n_pages = n_pages;
+  const int esz = elem_size_of(*col);
+  h->elem_size = esz;
+  if (col->physical_type < 0 || col->physical_type > PQD_FIXED_LEN_BYTE_ARRAY) return fail_arg("unknown physical type");
+  if (col->physical_type == PQD_FIXED_LEN_BYTE_ARRAY && col->type_length < 0) return fail_arg("negative type_length");
+  if (col->max_def < 0 || col->max_rep < 0) return fail_arg("negative max level");
+  if (reinterpret_cast<uintptr_t>(d_in) & 15u) return fail_arg("device chunk buffer must be 16-byte aligned");
+
+  // ---- host-side page table ----
+  h->h_pages.resize((size_t)n_pages);
+  int nd = 0, dict_page = -1, n_dict = 0;
+  int64_t slots = 0;
+  int host_status = PQD_OK, host_bad = -1;
+  bool any_dict_enc = false, any_plain = false, any_delta = false, any_other = false;
+  for (int p = 0; p < n_pages; p++) {
+    const pqd_page_desc &d = pages[p];
+    PageIn &pi = h->h_pages[(size_t)p];
+    if (d.offset < 0 || d.length < 0 || (uint64_t)d.offset + (uint64_t)d.length > len) return fail_arg("page outside the chunk buffer");
+    if (d.length > 0x7FFFFFF0ll) return fail_arg("page larger than 2 GiB");
+    pi.body_off = d.offset; pi.body_len = d.length; pi.page_type = d.page_type; pi.encoding = d.encoding;
+    pi.num_values = d.num_values; pi.rep_len = d.rep_len; pi.def_len = d.def_len; pi.slot_base = slots;
+    pi.data_idx = -1;
+    if (d.page_type == PQD_DATA_PAGE || d.page_type == PQD_DATA_PAGE_V2) {
+      pi.data_idx = nd++;
+      if (d.num_values > 0) slots += d.num_values;
+      if (is_dict_enc(d.encoding)) any_dict_enc = true;
+      else if (d.encoding == PQD_ENC_PLAIN) any_plain = true;
+      else if (d.encoding == PQD_ENC_DELTA_BINARY_PACKED) any_delta = true;
+      else any_other = true;
+    } else if (d.page_type == PQD_DICTIONARY_PAGE) {
+      if (n_dict == 0) dict_page = p;
+      n_dict++;
+    } else if (host_status == PQD_OK) {
+      host_status = PQD_ERR_UNSUPPORTED_PAGE_TYPE; host_bad = p;   // INDEX_PAGE and unknown types, layout/page.go:813,934
+    }
+  }
+  if (n_dict > 1) return fail_arg("more than one dictionary page in a chunk is not supported");
+  h->nd = nd;
+  h->total_slots = slots;
+  const bool is_bytes = col->physical_type == PQD_BYTE_ARRAY;
+  if (is_bytes) { g_last_error = "BYTE_ARRAY columns are not implemented yet"; return PQD_ERR_UNSUPPORTED_TYPE; }
+  (void)any_other;
+
+  // ---- meta block: pages | state | streams | tile prefixes | totals | status ----
+  const size_t n_streams = (size_t)3 * nd;
+  std::vector<Stream> h_streams(n_streams);
+  std::vector<int32_t> tp_levels(2 * (size_t)nd + 1, 0), tp_dict((size_t)nd + 1, 0), tp_plain((size_t)nd + 1, 0);
+  int64_t run_total = 0, tile_total = 0;
+  {
+    std::memset(h_streams.data(), 0, n_streams * sizeof(Stream));
+    int64_t t_lv = 0, t_dc = 0, t_pl = 0;
+    for (int g = 0; g < 3; g++) {
+      for (int p = 0; p < n_pages; p++) {
+        const PageIn &pi = h->h_pages[(size_t)p];
+        if (pi.data_idx < 0) continue;
+        const int d = pi.data_idx;
+        Stream &s = h_streams[(size_t)g * nd + d];
+        const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
+        const bool want = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) || (g == 2 && is_dict_enc(pi.encoding));
+        const int64_t tiles = want ? (nv + kTile - 1) / kTile : 0;
+        const int64_t rcap = want ? std::min<int64_t>(nv, pi.body_len) + 2 : 0;
+        s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total; s.page = p;
+        run_total += rcap;
+        tile_total += tiles + 1;
+        if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
+        if (g < 2) { tp_levels[(size_t)g * nd + d] = (int32_t)t_lv; t_lv += tiles; }
+        else {
+          tp_dict[(size_t)d] = (int32_t)t_dc; t_dc += tiles;
+          tp_plain[(size_t)d] = (int32_t)t_pl;
+          if (pi.encoding == PQD_ENC_PLAIN) {
+            const int64_t units = col->physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)esz;
+            t_pl += (units + kPlainTile - 1) / kPlainTile;
+          }
+        }
+        if (t_lv > 0x7FFFFFF0ll || t_dc > 0x7FFFFFF0ll || t_pl > 0x7FFFFFF0ll) return fail_arg("chunk too large (tiles)");
+      }
+    }
+    tp_levels[2 * (size_t)nd] = (int32_t)t_lv;
+    tp_dict[(size_t)nd] = (int32_t)t_dc;
+    tp_plain[(size_t)nd] = (int32_t)t_pl;
+  }
+  const size_t off_pages = 0;
+  const size_t off_state = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
+  const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
+  const size_t off_tp_lv = align_up(off_streams + sizeof(Stream) * n_streams, 256);
+  const size_t off_tp_dc = align_up(off_tp_lv + 4 * tp_levels.size(), 256);
+  const size_t off_tp_pl = align_up(off_tp_dc + 4 * tp_dict.size(), 256);
+  const size_t meta_bytes = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
+  int rc;
+  if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(meta_bytes))) return rc;
+  if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
+  {
+    uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
+    std::memset(m, 0, meta_bytes);
+    std::memcpy(m + off_pages, h->h_pages.data(), sizeof(PageIn) * (size_t)n_pages);
+    std::memcpy(m + off_streams, h_streams.data(), sizeof(Stream) * n_streams);
+    std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
+    std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
+    std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
+  }
+  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, meta_bytes, hipMemcpyHostToDevice, h->stream));
+
+  // ---- workspaces and outputs ----
+  if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
+  if ((rc = h->tile_run.ensure(4 * (size_t)(tile_total + 64)))) return rc;
+  const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
+  if ((rc = h->values.ensure(val_bytes))) return rc;
+  const bool nullable = col->max_def > 0;
+  if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
+  if (col->max_def > 0 && (rc = h->def.ensure(4 * (size_t)slots + 64))) return rc;
+  if (col->max_rep > 0 && (rc = h->rep.ensure(4 * (size_t)slots + 64))) return rc;
+  int dict_n = 0;
+  if (dict_page >= 0) {
+    dict_n = h->h_pages[(size_t)dict_page].num_values;
+    if (dict_n < 0) dict_n = 0;
+    if ((rc = h->dict.ensure((size_t)dict_n * (size_t)esz + 64))) return rc;
+  }
+
+  uint8_t *mb = static_cast<uint8_t *>(h->meta.p);
+  ChunkCtx c;
+  c.in = d_in; c.in_len = (int64_t)len;
+  c.pages = reinterpret_cast<const PageIn *>(mb + off_pages);
+  c.state = reinterpret_cast<PageState *>(mb + off_state);
+  c.streams = reinterpret_cast<Stream *>(mb + off_streams);
+  c.runs = static_cast<RunEntry *>(h->runs.p);
+  c.tile_run = static_cast<int32_t *>(h->tile_run.p);
+  c.n_pages = n_pages; c.nd = nd; c.max_def = col->max_def; c.max_rep = col->max_rep;
+  c.physical_type = col->physical_type; c.type_length = col->type_length; c.elem_size = esz;
+  c.chunk_status = static_cast<int32_t *>(h->small.p) + 16;
+  h->ctx = c;
+  const int32_t *d_tp_lv = reinterpret_cast<const int32_t *>(mb + off_tp_lv);
+  const int32_t *d_tp_dc = reinterpret_cast<const int32_t *>(mb + off_tp_dc);
+  const int32_t *d_tp_pl = reinterpret_cast<const int32_t *>(mb + off_tp_pl);
+  int64_t *d_totals = static_cast<int64_t *>(h->small.p);
+
+  uint8_t *dense_out = static_cast<uint8_t *>(nullable ? h->dense.p : h->values.p);
+
+  // ---- kernels ----
+  if (n_pages > 0) {
+    { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
+    if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
+      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, h->stream)); }
+      { Prof pf(h, "k_hybrid_expand<levels>");
+        HIP_TRY(launch_expand_levels(c, d_tp_lv, tp_levels.back(), static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
+    }
+  }
+  { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
+  if (dict_page >= 0) {
+    if (h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN && h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN_DICTIONARY) {
+      // the reference decodes every dictionary page as PLAIN whatever its header says (layout/page.go:802)
+    }
+    if (col->physical_type == PQD_BOOLEAN) { g_last_error = "BOOLEAN dictionary pages are not implemented"; return PQD_ERR_UNSUPPORTED_TYPE; }
+    Prof pf(h, "k_dict_plain_fixed");
+    HIP_TRY(launch_dict_plain_fixed(c, dict_page, static_cast<uint8_t *>(h->dict.p), h->stream));
+  }
+  if (any_dict_enc) {
+    if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
+    else {
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
+      { Prof pf(h, "k_hybrid_expand<dict>");
+        HIP_TRY(launch_expand_dict(c, d_tp_dc, tp_dict.back(), static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->n_cu, h->stream)); }
+    }
+  }
+  if (any_plain) {
+    if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+    else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+  }
+  if (any_delta) {
+    if (col->physical_type != PQD_INT32 && col->physical_type != PQD_INT64) {
+      host_status = host_status ? host_status : PQD_ERR_UNSUPPORTED_ENCODING;  // layout/page.go:682
+    } else {
+      Prof pf(h, "k_delta_decode");
+      HIP_TRY(launch_delta_decode(c, dense_out, h->stream));
+    }
+  }
+  if (any_other && host_status == PQD_OK) {
+    for (int p = 0; p < n_pages; p++) {
+      const PageIn &pi = h->h_pages[(size_t)p];
+      if (pi.data_idx < 0) continue;
+      const int e = pi.encoding;
+      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_BINARY_PACKED) {
+        host_status = PQD_ERR_UNSUPPORTED_ENCODING; host_bad = p; break;
+      }
+    }
+  }
+  if (nullable && slots > 0) {
+    const int n_tiles = (int)((slots + 4095) / 4096);
+    if ((rc = h->scratch.ensure(8 * (size_t)n_tiles + 64))) return rc;
+    Prof pf(h, "k_scatter");
+    HIP_TRY(launch_scatter_fixed(c, static_cast<const int32_t *>(h->def.p), static_cast<const uint8_t *>(h->dense.p),
+                                 static_cast<uint8_t *>(h->values.p), slots, static_cast<int64_t *>(h->scratch.p), h->stream));
+  }
+  { Prof pf(h, "k_collect_status"); HIP_TRY(launch_collect_status(c, c.chunk_status, h->stream)); }
+  HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
+
+  h->result = pqd_chunk_result{};
+  h->result.status = host_status;
+  h->result.bad_page = host_bad;
+  h->busy = true;
+  return PQD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pqd_version(void) { return "pqdecode 0.1 (gfx950)"; }
+const char *pqd_last_error(void) { return g_last_error.c_str(); }
+
+const char *pqd_strerror(int code) {
+  switch (code) {
+    case PQD_OK: return "ok";
+    case PQD_ERR_EOF: return "EOF";
+    case PQD_ERR_UNEXPECTED_EOF: return "unexpected EOF";
+    case PQD_ERR_MALFORMED: return "malformed page";
+    case PQD_ERR_UNSUPPORTED_ENCODING: return "unsupported encoding";
+    case PQD_ERR_UNSUPPORTED_PAGE_TYPE: return "unsupported page type";
+    case PQD_ERR_UNSUPPORTED_TYPE: return "unsupported physical type / encoding combination";
+    case PQD_ERR_BIT_WIDTH: return "unsupported bit width";
+    case PQD_ERR_INVALID_ARG: return "invalid argument";
+    case PQD_ERR_HIP: return "HIP runtime error";
+    case PQD_ERR_NOMEM: return "out of memory";
+    case PQD_ERR_NO_DICTIONARY: return "dictionary-encoded page without a dictionary page";
+    case PQD_ERR_THRIFT: return "page header could not be parsed";
+    default: return "unknown error";
+  }
+}
+
+int pqd_device_count(int *n_out) {
+  if (!n_out) return fail_arg("n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *n_out = 0; return fail_hip(e, "hipGetDeviceCount"); }
+  *n_out = n;
+  return PQD_OK;
+}
+
+int pqd_handle_create(int device, void *stream, pqd_handle **out) {
+  if (!out) return fail_arg("out is NULL");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail_arg("no such device");
+  Guard g(device);
+  pqd_handle *h = new pqd_handle();
+  h->device = device;
+  if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail_hip(e, "hipStreamCreate"); }
+    h->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+  *out = h;
+  return PQD_OK;
+}
+
+int pqd_handle_destroy(pqd_handle *h) {
+  if (!h) return PQD_OK;
+  Guard g(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+  DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
+                    &h->offsets, &h->bytes, &h->scratch, &h->small};
+  for (DevBuf *b : bufs) b->release();
+  h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PQD_OK;
+}
+
+int pqd_set_profiling(pqd_handle *h, int on) {
+  if (!h) return fail_arg("handle is NULL");
+  h->profiling = on != 0;
+  return PQD_OK;
+}
+
+int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
+                            const pqd_column_desc *col) {
+  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !d_chunk)) return fail_arg("NULL argument");
+  Guard g(h->device);
+  return decode_on_device(h, static_cast<const uint8_t *>(d_chunk), len, pages, n_pages, col);
+}
+
+int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
+                     const pqd_column_desc *col) {
+  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !chunk)) return fail_arg("NULL argument");
+  Guard g(h->device);
+  int rc;
+  const size_t padded = align_up(len + 64, 256);
+  if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
+  // the caller's memory may not be retained (cgo rule): copy into pinned staging, then DMA
+  HIP_TRY(hipStreamSynchronize(h->stream));  // the previous chunk may still be reading the staging buffer
+  std::memcpy(h->stage_in.p, chunk, len);
+  std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
+  HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
+  return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col);
+}
+
+int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
+  if (!h) return fail_arg("handle is NULL");
+  Guard g(h->device);
+  if (h->busy) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->busy = false;
+    const int64_t *tot = static_cast<const int64_t *>(h->host_small.p);
+    const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + 16;
+    pqd_chunk_result &r = h->result;
+    r.num_slots = tot[0]; r.num_values = tot[1]; r.num_nulls = tot[2]; r.num_rows = tot[3];
+    r.bytes_len = 0;
+    r.elem_size = h->elem_size;
+    r.has_levels = (h->col.max_def > 0 ? 1 : 0) | (h->col.max_rep > 0 ? 2 : 0);
+    if (r.status == PQD_OK) { r.status = st[0]; r.bad_page = st[1]; }
+    else if (st[0] != 0 && st[1] >= 0 && (r.bad_page < 0 || st[1] < r.bad_page)) { r.status = st[0]; r.bad_page = st[1]; }
+    if (r.status == PQD_OK) r.bad_page = -1;
+    h->have_result = true;
+  }
+  if (!h->have_result) return fail_arg("no decode call to wait for");
+  if (res) *res = h->result;
+  return h->result.status;
+}
+
+int pqd_result_device(pqd_handle *h, pqd_device_result *out) {
+  if (!h || !out) return fail_arg("NULL argument");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  out->values = h->values.p;
+  out->def_levels = h->col.max_def > 0 ? static_cast<int32_t *>(h->def.p) : nullptr;
+  out->rep_levels = h->col.max_rep > 0 ? static_cast<int32_t *>(h->rep.p) : nullptr;
+  out->offsets = nullptr;
+  out->bytes = nullptr;
+  return PQD_OK;
+}
+
+int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_levels, int64_t *offsets, uint8_t *bytes) {
+  if (!h) return fail_arg("handle is NULL");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  Guard g(h->device);
+  const size_t n = (size_t)h->total_slots;
+  if (values && n) HIP_TRY(hipMemcpyAsync(values, h->values.p, n * (size_t)h->elem_size, hipMemcpyDeviceToHost, h->stream));
+  if (def_levels) {
+    if (h->col.max_def > 0) { if (n) HIP_TRY(hipMemcpyAsync(def_levels, h->def.p, 4 * n, hipMemcpyDeviceToHost, h->stream)); }
+    else std::memset(def_levels, 0, 4 * n);
+  }
+  if (rep_levels) {
+    if (h->col.max_rep > 0) { if (n) HIP_TRY(hipMemcpyAsync(rep_levels, h->rep.p, 4 * n, hipMemcpyDeviceToHost, h->stream)); }
+    else std::memset(rep_levels, 0, 4 * n);
+  }
+  (void)offsets; (void)bytes;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
+int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages) {
+  if (!h || !out) return fail_arg("NULL argument");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  Guard g(h->device);
+  const int n = std::min<int>(cap_pages, h->n_pages);
+  if (n <= 0) return PQD_OK;
+  std::vector<PageState> st((size_t)n);
+  HIP_TRY(hipMemcpy(st.data(), h->ctx.state, sizeof(PageState) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int p = 0; p < n; p++) {
+    const bool data = h->h_pages[(size_t)p].data_idx >= 0;
+    out[3 * p + 0] = data ? st[(size_t)p].n_nulls : 0;
+    out[3 * p + 1] = data ? st[(size_t)p].n_rows : 0;
+    out[3 * p + 2] = data ? std::max(h->h_pages[(size_t)p].num_values, 0) : 0;
+  }
+  return PQD_OK;
+}
+
+// Not part of the public header: prints the device-side page and stream tables of the last call.
+int pqd_debug_dump(pqd_handle *h) {
+  if (!h || !h->have_result) return PQD_ERR_INVALID_ARG;
+  Guard g(h->device);
+  std::vector<PageState> st((size_t)h->n_pages);
+  std::vector<Stream> ss((size_t)3 * h->nd);
+  if (h->n_pages) HIP_TRY(hipMemcpy(st.data(), h->ctx.state, sizeof(PageState) * st.size(), hipMemcpyDeviceToHost));
+  if (h->nd) HIP_TRY(hipMemcpy(ss.data(), h->ctx.streams, sizeof(Stream) * ss.size(), hipMemcpyDeviceToHost));
+  for (int p = 0; p < h->n_pages; p++) {
+    const PageState &x = st[(size_t)p];
+    const PageIn &pi = h->h_pages[(size_t)p];
+    std::fprintf(stderr, "page %d type %d enc %d nv %d body [%lld,+%lld) | status %d nulls %d rows %d cnt %d dense_base %lld val [%lld,+%lld) aux %lld %lld\n",
+                 p, pi.page_type, pi.encoding, pi.num_values, (long long)pi.body_off, (long long)pi.body_len, x.status, x.n_nulls,
+                 x.n_rows, x.cnt, (long long)x.dense_base, (long long)x.val_off, (long long)x.val_len, (long long)x.aux0, (long long)x.aux1);
+  }
+  for (size_t i = 0; i < ss.size(); i++) {
+    const Stream &x = ss[i];
+    std::fprintf(stderr, "stream %zu (group %zu) off %lld len %d avail %d w %d cnt %d out_base %lld run_base %lld cap %d tile_base %d page %d | n_runs %d status %d decoded %lld\n",
+                 i, h->nd ? i / (size_t)h->nd : 0, (long long)x.off, x.len, x.avail, x.w, x.cnt, (long long)x.out_base, (long long)x.run_base,
+                 x.run_cap, x.tile_base, x.page, x.n_runs, x.status, (long long)x.decoded);
+  }
+  return PQD_OK;
+}
+
+int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out) {
+  if (!h || !n_out) return fail_arg("NULL argument");
+  Guard g(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int n = 0;
+  for (size_t i = 0; i < h->n_events; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->events[i].start, h->events[i].stop) != hipSuccess) continue;
+    int j = 0;
+    for (; j < n; j++) if (std::strcmp(out[j].name, h->events[i].name) == 0) break;
+    if (j == n) {
+      if (n >= cap) continue;
+      std::memset(&out[n], 0, sizeof out[n]);
+      std::strncpy(out[n].name, h->events[i].name, sizeof(out[n].name) - 1);
+      n++;
+    }
+    out[j].ms += ms;
+    out[j].launches += 1;
+  }
+  *n_out = n;
+  return PQD_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime with the same SONAME as the system one libpqdecode.so links to; whichever is
+# loaded first serves both, and only torch's works for torch.  Tests that use both need torch imported first.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,268 @@
+"""GPU parity: libpqdecode.so (HIP kernels, through the C ABI) against the CPU oracle on the same
+seeded chunks.  Bit-exact: values, levels, counts and error classes."""
+import numpy as np
+import pytest
+
+import pagegen as pg
+
+pytestmark = pytest.mark.gpu
+
+PHYS_DT = {pg.INT32: "<i4", pg.INT64: "<i8", pg.FLOAT: "<f4", pg.DOUBLE: "<f8"}
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import parquet_go_amd as pq
+    d = pq.Decoder(0)
+    yield d
+    d.close()
+
+
+def check_same(dec, oracle, chunk, pages, ptype, type_length=0, max_def=0, max_rep=0):
+    g = dec.decode(chunk, pages, ptype, type_length, max_def, max_rep)
+    o = oracle.read_chunk(chunk, pages, ptype, type_length, max_def, max_rep)
+    assert g.status == o.status, "status gpu=%d oracle=%d (gpu page %d, oracle page %d)" % (g.status, o.status, g.bad_page, o.bad_page)
+    if o.status != 0:
+        assert g.bad_page == o.bad_page
+        return g, o
+    assert (g.n_slots, g.n_rows, g.n_nulls) == (o.n_slots, o.n_rows, o.n_nulls)
+    assert np.array_equal(g.def_levels, o.def_levels)
+    assert np.array_equal(g.rep_levels, o.rep_levels)
+    assert g.kind == o.kind
+    if o.kind == "fixed":
+        assert g.values.shape == o.values.shape
+        if not np.array_equal(g.values, o.values):
+            bad = np.nonzero((g.values != o.values).any(axis=1))[0]
+            raise AssertionError("values differ at %d slots, first %d: gpu %s oracle %s" % (
+                len(bad), bad[0], g.values[bad[0]].tolist(), o.values[bad[0]].tolist()))
+    else:
+        assert np.array_equal(g.offsets, o.offsets)
+        assert np.array_equal(g.bytes, o.bytes)
+    return g, o
+
+
+def rand_dict(rng, ptype, n, type_length=0):
+    if ptype in PHYS_DT:
+        nbytes = np.dtype(PHYS_DT[ptype]).itemsize
+    elif ptype == pg.INT96:
+        nbytes = 12
+    else:
+        nbytes = type_length
+    return rng.integers(0, 256, n * nbytes, dtype=np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("w", [0, 1, 2, 3, 4, 5, 7, 8, 11, 12, 15, 16, 17, 20, 24, 30, 31, 32])
+def test_dict_int32_widths(dec, oracle, w):
+    rng = np.random.default_rng(100 + w)
+    nd = min(1 << w, 70000) if w else 1
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 9)), lead=int(rng.integers(0, 5)))
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    for n, style in ((1, "mixed"), (8, "bp"), (4095, "mixed"), (4096, "arrow"), (4097, "rle"), (20000, "mixed"), (70001, "bp")):
+        idx = rng.integers(0, nd, n)
+        for r in rng.integers(0, n, 10):
+            idx[r:r + int(rng.integers(2, 400))] = idx[r]
+        if style == "rle" and n > 3000:
+            idx = np.repeat(idx[:n // 7 + 1], 7)[:n]
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(idx, w, rng, style))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32)
+
+
+@pytest.mark.parametrize("ptype,tl", [(pg.INT64, 0), (pg.FLOAT, 0), (pg.DOUBLE, 0), (pg.INT96, 0),
+                                      (pg.FIXED_LEN_BYTE_ARRAY, 5), (pg.FIXED_LEN_BYTE_ARRAY, 16)])
+def test_dict_other_types(dec, oracle, ptype, tl):
+    rng = np.random.default_rng(7 + ptype + tl)
+    nd = 1000
+    cb = pg.ChunkBuilder(gap=1)
+    cb.dict_page(rand_dict(rng, ptype, nd, tl), nd)
+    for n in (3, 5000, 12345):
+        idx = rng.integers(0, nd, n)
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, pg.dict_indices_body(idx, 10, rng, "mixed"))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, ptype, tl)
+
+
+def test_dict_large_dictionary_global_gather(dec, oracle):
+    rng = np.random.default_rng(9)
+    nd = 65536
+    cb = pg.ChunkBuilder()
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    idx = rng.integers(0, nd, 300000)
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, len(idx), pg.dict_indices_body(idx, 16, rng, "bp"))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32)
+
+
+def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
+    # what the reference's own writer emits: width 32, RLE runs only (layout/dictpage.go:155-158), 8 KiB pages
+    rng = np.random.default_rng(10)
+    nd = 500
+    cb = pg.ChunkBuilder(gap=20)
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    for _ in range(40):
+        n = int(rng.integers(1500, 2100))
+        idx = rng.integers(0, nd, n)
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([32]) + oracle.write_rle_int32(idx.astype(np.int32), 32))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32)
+
+
+@pytest.mark.parametrize("ptype,tl", [(pg.INT32, 0), (pg.INT64, 0), (pg.FLOAT, 0), (pg.DOUBLE, 0), (pg.INT96, 0),
+                                      (pg.FIXED_LEN_BYTE_ARRAY, 7), (pg.BOOLEAN, 0)])
+def test_plain_fixed(dec, oracle, ptype, tl):
+    rng = np.random.default_rng(20 + ptype)
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 7)), lead=3)
+    for n in (1, 15, 16, 17, 4099, 100003):
+        if ptype == pg.BOOLEAN:
+            body = oracle.write_plain_boolean(rng.integers(0, 2, n, dtype=np.uint8))
+        else:
+            body = rand_dict(rng, ptype, n, tl)
+        cb.data_page_v1(pg.ENC_PLAIN, n, body)
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, ptype, tl)
+
+
+@pytest.mark.parametrize("dtype,ptype", [(np.int32, pg.INT32), (np.int64, pg.INT64)])
+def test_delta_binary_packed(dec, oracle, dtype, ptype):
+    rng = np.random.default_rng(30 + ptype)
+    info = np.iinfo(dtype)
+    cb = pg.ChunkBuilder(gap=5, lead=1)
+    for n in (1, 2, 33, 128, 129, 130, 257, 5000, 40001):
+        for spread, trim in ((0, False), (3, True), (1000, False), (1 << 20, True), (None, False)):
+            if spread is None:
+                vals = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
+            else:
+                vals = (np.cumsum(rng.integers(-spread, spread + 1, n)) + 1_700_000_000).astype(dtype)
+            enc = pg.delta_encode(vals, dtype, trim=trim) if n < 6000 else pg.delta_encode_fast(vals, dtype)
+            cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, n, enc)
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, ptype)
+
+
+def test_delta_reference_writer_and_other_geometries(dec, oracle):
+    rng = np.random.default_rng(33)
+    cb = pg.ChunkBuilder()
+    # restated parquet-go writer, incl. the wrap-around inputs of encodingread_test.go:153
+    cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, 5, oracle.write_delta_int64(
+        [9223372036854775807, -9223372036854775808, -15654523568543623, 4354365463543632, 0]))
+    for block, n_mb in ((256, 8), (128, 2), (64, 2), (512, 4), (128, 16)):
+        vals = np.cumsum(rng.integers(-5000, 5000, 3000)).astype(np.int64)
+        cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, len(vals), pg.delta_encode(vals, np.int64, block, n_mb))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT64)
+
+
+def _levels(rng, n, max_def, max_rep):
+    dl = rng.integers(0, max_def + 1, n) if max_def else np.zeros(n, np.int64)
+    # long stretches of equal levels, as real columns have
+    for r in rng.integers(0, n, max(1, n // 200)):
+        dl[r:r + int(rng.integers(5, 300))] = max_def
+    rl = np.zeros(n, np.int64)
+    if max_rep:
+        rl = rng.integers(0, max_rep + 1, n)
+        rl[0] = 0
+    return dl, rl
+
+
+@pytest.mark.parametrize("max_def,max_rep", [(1, 0), (3, 1), (2, 2), (7, 0)])
+@pytest.mark.parametrize("enc", ["plain", "dict", "delta"])
+def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
+    rng = np.random.default_rng(40 + max_def * 10 + max_rep)
+    cb = pg.ChunkBuilder(gap=2)
+    nd = 300
+    dict_vals = rng.integers(-2**62, 2**62, nd, dtype=np.int64)
+    if enc == "dict":
+        cb.dict_page(dict_vals.tobytes(), nd)
+    for n, v2 in ((1, False), (100, True), (4096, False), (9000, True), (50000, False)):
+        dl, rl = _levels(rng, n, max_def, max_rep)
+        nn = int((dl == max_def).sum())
+        if enc == "plain":
+            body, e = rng.integers(-2**62, 2**62, nn, dtype=np.int64).tobytes(), pg.ENC_PLAIN
+        elif enc == "dict":
+            body, e = pg.dict_indices_body(rng.integers(0, nd, nn), 9, rng), pg.ENC_RLE_DICTIONARY
+        else:
+            body = pg.delta_encode_fast(np.cumsum(rng.integers(0, 1000, nn)).astype(np.int64)) if nn else b""
+            e = pg.ENC_DELTA_BINARY_PACKED
+        if v2:
+            cb.data_page_v2(e, n, body, pg.hybrid_encode(rl, int(max_rep).bit_length(), rng) if max_rep else b"",
+                            pg.hybrid_encode(dl, int(max_def).bit_length(), rng))
+        else:
+            cb.data_page_v1(e, n, body, pg.level_block_v1(rl, max_rep, rng) if max_rep else b"",
+                            pg.level_block_v1(dl, max_def, rng, "arrow"))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
+
+
+def test_empty_and_all_null(dec, oracle):
+    cb = pg.ChunkBuilder()
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk or b"\0", pages, pg.INT32)
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(pg.ENC_PLAIN, 0, b"")
+    cb.data_page_v1(pg.ENC_PLAIN, 500, b"", b"", pg.level_block_v1(np.zeros(500, np.int64), 1))   # all null
+    cb.data_page_v1(pg.ENC_PLAIN, 3, np.arange(3, dtype=np.int32).tobytes(), b"", pg.level_block_v1(np.ones(3, np.int64), 1))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32, 0, 1, 0)
+
+
+def test_error_classes(dec, oracle):
+    def one(build, ptype=pg.INT32, **kw):
+        cb = pg.ChunkBuilder(lead=2)
+        good = np.arange(4, dtype=np.int32 if ptype == pg.INT32 else np.int64).tobytes()
+        cb.data_page_v1(pg.ENC_PLAIN, 4, good, b"", pg.level_block_v1(np.ones(4, np.int64), 1) if kw.get("max_def") else b"")
+        build(cb)
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, ptype, **kw)
+        assert o.status != 0
+        return o.status
+
+    d4 = np.arange(4, dtype=np.int32).tobytes()
+    # dictionary index out of range
+    assert one(lambda cb: (cb.dict_page(d4, 4), cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, 8, pg.dict_indices_body(np.array([0, 1, 2, 3, 4, 0, 0, 0]), 3, style="bp")))) == oracle.PANIC
+    # fewer indices than the page needs
+    assert one(lambda cb: (cb.dict_page(d4, 4), cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, 9, pg.dict_indices_body(np.zeros(8, np.int64), 2, style="bp")))) == oracle.PANIC
+    # PLAIN section too short / empty
+    assert one(lambda cb: cb.data_page_v1(pg.ENC_PLAIN, 10, b"\0" * 39)) == oracle.UNEXPECTED_EOF
+    assert one(lambda cb: cb.data_page_v1(pg.ENC_PLAIN, 10, b"")) == oracle.EOF
+    # bit-packed run whose payload is missing entirely
+    assert one(lambda cb: (cb.dict_page(d4, 4), cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 8, bytes([2, 3])))) == oracle.EOF
+    # truncated level section
+    assert one(lambda cb: cb.data_page_v1(pg.ENC_PLAIN, 10, b"", b"", b"\x05\x00"), max_def=1) == oracle.UNEXPECTED_EOF
+    # delta stream announcing fewer values than the page holds
+    assert one(lambda cb: cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, 10, pg.delta_encode(np.arange(5), np.int64)), ptype=pg.INT64) == oracle.PANIC
+    # delta stream cut in the middle of a block
+    enc = pg.delta_encode(np.cumsum(np.arange(300) % 7 * 1000), np.int64)
+    assert one(lambda cb: cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, 300, enc[:len(enc) // 2]), ptype=pg.INT64) == oracle.EOF
+    # unsupported encodings
+    assert one(lambda cb: cb.data_page_v1(4, 10, b"\0" * 40)) == oracle.UNSUPPORTED
+
+
+def test_truncated_bit_packed_run_is_zero_filled(dec, oracle):
+    # a final bit-packed run cut short by the end of the page decodes to zeros where bytes are missing
+    # (encodingread.go:188-191) as long as one byte is left
+    cb = pg.ChunkBuilder()
+    cb.dict_page(np.arange(8, dtype=np.int32).tobytes(), 8)
+    body = pg.dict_indices_body(np.arange(16) % 8, 3, style="bp")
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 16, body[:-2])
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
+    assert o.status == 0
+
+
+def test_device_resident_entry_point(dec, oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    cb = pg.ChunkBuilder(lead=16)
+    nd = 4096
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    idx = rng.integers(0, nd, 250000)
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, len(idx), pg.dict_indices_body(idx, 12, rng, "arrow"))
+    chunk, pages = cb.finish()
+    t = torch.frombuffer(bytearray(chunk), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    dec._is_bytes = False
+    dec.submit_device(t.data_ptr(), t.numel(), pages, pg.INT32)
+    g = dec.fetch()
+    del t
+    o = oracle.read_chunk(chunk, pages, oracle.INT32)
+    assert g.status == 0 and np.array_equal(g.values, o.values)
