@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the page-decode path on MI355X.
+
+Workload (BASELINE.json configs[1]): an INT32 RLE_DICTIONARY column chunk of 256 Mi values per GPU, decoded once
+for each bit width in {1,2,4,8,12,16,20} (dictionary min(2^w, 65536) entries, UNCOMPRESSED v1 data pages of
+1 Mi values, run mix ~90 % bit-packed / ~10 % RLE).  One step = one decode of the chunk at every width, inputs
+already resident in HBM, outputs left in HBM.  value = decoded output bytes / wall time, summed over ranks.
+
+    python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch  # first: its bundled HIP runtime must be the one in the process (see tests/conftest.py)
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import parquet_go_amd as pq  # noqa: E402
+from gen import pqgen  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--values", type=int, default=256 << 20, help="values per GPU in the column chunk")
+    ap.add_argument("--page-values", type=int, default=1 << 20)
+    ap.add_argument("--widths", type=str, default="1,2,4,8,12,16,20")
+    ap.add_argument("--cpu-pages", type=int, default=24, help="pages per width decoded by the CPU oracle (baseline sample)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the DELTA_BINARY_PACKED / host-to-host extras")
+    ap.add_argument("--delta-values", type=int, default=512 << 20)
+    return ap.parse_args()
+
+
+def to_device(a):
+    t = torch.empty(a.size + 64, dtype=torch.uint8, device="cuda")
+    t[:a.size].copy_(torch.from_numpy(a))
+    t[a.size:].zero_()
+    return t
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    widths = [int(x) for x in args.widths.split(",")]
+    n_values, page_values = args.values, args.page_values
+
+    # ---- synthetic inputs, generated on the host and parked in HBM ----
+    t_gen = time.time()
+    work = []
+    for w in widths:
+        dict_n = min(1 << w, 65536)
+        chunk, pages = pqgen.dict_chunk(0x5EED0002 + 1000 * rank + w, n_values, w, dict_n, page_values)
+        work.append({"w": w, "dict_n": dict_n, "pages": pages, "dev": to_device(chunk), "nbytes": chunk.size,
+                     "in_bytes": int(pages["length"].sum()), "host": chunk if rank == 0 else None})
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    dec = pq.Decoder(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=True)
+    ktimes = {}
+
+    def decode(item, collect=False):
+        dec.submit_device(item["dev"].data_ptr(), item["nbytes"], item["pages"], pq.INT32)
+        r = dec.wait()
+        if r.status != 0:
+            raise RuntimeError("decode failed: status %d at page %d (w=%d)" % (r.status, r.bad_page, item["w"]))
+        if collect:
+            for name, (ms, n) in dec.kernel_times().items():
+                e = ktimes.setdefault((item["w"], name), [0.0, 0])
+                e[0] += ms
+                e[1] += n
+        return r
+
+    # ---- verification against the CPU oracle (untimed) + CPU baseline on a bounded sample ----
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import oracle as orc
+        cpu_vals, cpu_s = 0, 0.0
+        for item in work:
+            k = min(args.cpu_pages, len(item["pages"]) - 1)
+            sample_pages = item["pages"][:1 + k]
+            t0 = time.time()
+            o = orc.read_chunk(item["host"], sample_pages, orc.INT32)
+            cpu_s += time.time() - t0
+            assert o.status == 0, "oracle failed on the sample"
+            cpu_vals += o.n_slots
+            decode(item)
+            g = dec.fetch()
+            gv = g.values.view("<i4").reshape(-1)
+            if not np.array_equal(gv[:o.n_slots], o.values.view("<i4").reshape(-1)):
+                raise RuntimeError("GPU output differs from the oracle at w=%d" % item["w"])
+            del g, gv, o
+        cpu = {"value": round(cpu_vals * 4 / cpu_s / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+               "sample": "first %d pages (%d Mi values) of each of the %d widths, decoded by oracle/pq_oracle.c "
+                         "(C restatement of the Go decoders; typed vectors instead of boxed interface{}), "
+                         "output checked equal to the GPU's" % (args.cpu_pages, args.cpu_pages * page_values >> 20, len(widths))}
+    for item in work:
+        item["host"] = None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        for item in work:
+            decode(item)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for item in work:
+            decode(item, collect=True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out_bytes_step = len(widths) * n_values * 4
+    value = world * out_bytes_step * args.steps / elapsed / 1e9
+
+    # ---- roofline of the dominant kernel (expand + gather), from HIP events around each launch ----
+    per_width = {}
+    exp_ms = exp_bytes = 0.0
+    exp_n = 0
+    all_ms = {}
+    for (w, name), (ms, n) in ktimes.items():
+        all_ms[name] = all_ms.get(name, 0.0) + ms
+    for item in work:
+        w = item["w"]
+        ms, n = ktimes.get((w, "k_hybrid_expand<dict>"), (0.0, 0))
+        pre_ms, _ = ktimes.get((w, "k_hybrid_prescan(dict)"), (0.0, 0))
+        alg = item["in_bytes"] + n_values * 4 + item["dict_n"] * 4  # packed input + decoded output + dictionary
+        if n:
+            per_width[str(w)] = {"expand_ms": round(ms / n, 4), "prescan_ms": round(pre_ms / n, 4),
+                                 "expand_GBps": round(alg / (ms / n) / 1e6, 1),
+                                 "alg_bytes_per_value": round(alg / n_values, 4)}
+            exp_ms += ms
+            exp_bytes += alg * n
+            exp_n += n
+    achieved = exp_bytes / exp_ms / 1e6 if exp_ms else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_hybrid_expand<dict> (bit unpack + dictionary gather)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "avg_launch_ms": round(exp_ms / exp_n, 4) if exp_n else None, "per_width": per_width,
+                "kernel_ms_share": {k: round(v / max(sum(all_ms.values()), 1e-9), 4) for k, v in all_ms.items()}}
+
+    extra = {}
+    if rank == 0 and not args.no_extra:
+        extra = run_extras(args, dec, local_rank)
+
+    if rank == 0:
+        res = {
+            "metric": "device-resident decoded GB/s, INT32 RLE_DICTIONARY (bit widths 1-20)",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: INT32 RLE_DICTIONARY column chunk, %d Mi values per GPU, one decode per bit "
+                                   "width in %s, dictionary min(2^w,65536) entries, UNCOMPRESSED v1 pages of %d Ki values, "
+                                   "~90%% bit-packed / ~10%% RLE runs; input and output resident in HBM"
+                                   % (n_values >> 20, widths, page_values >> 10),
+                       "values_per_gpu": n_values, "page_values": page_values, "widths": widths,
+                       "gen_seconds": round(t_gen, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run_extras(args, dec, local_rank):
+    """Secondary numbers kept next to the headline: DELTA_BINARY_PACKED INT64 (configs[2]) device-resident, and the
+    host-to-host rate (pinned staging + H2D + decode + D2H) of one dictionary chunk."""
+    extra = {}
+    try:
+        n = args.delta_values
+        chunk, pages = pqgen.delta_chunk(0x5EED0003, n, 12, 128 << 10)
+        dev = to_device(chunk)
+        torch.cuda.synchronize()
+        best = None
+        kt = {}
+        for i in range(4):
+            t0 = time.perf_counter()
+            dec.submit_device(dev.data_ptr(), chunk.size, pages, pq.INT64)
+            r = dec.wait()
+            dt = time.perf_counter() - t0
+            assert r.status == 0, r.status
+            if i:
+                best = dt if best is None else min(best, dt)
+                kt = dec.kernel_times()
+        in_bytes = int(pages["length"].sum())
+        kms = kt.get("k_delta_decode", (0.0, 1))[0]
+        extra["delta_int64"] = {"workload": "configs[2]: INT64 DELTA_BINARY_PACKED, %d Mi values, 128-value blocks / 4 miniblocks, "
+                                            "delta width 12, pages of 128 Ki values" % (n >> 20),
+                                "decoded_GBps": round(n * 8 / best / 1e9, 1), "ms": round(best * 1e3, 3),
+                                "kernel_ms": round(kms, 3),
+                                "kernel_alg_GBps": round((in_bytes + n * 8) / kms / 1e6, 1) if kms else None,
+                                "roofline_frac": round((in_bytes + n * 8) / kms / 1e6 / HBM_PEAK_GBPS, 4) if kms else None}
+        del dev
+    except Exception as e:  # the extras never take the headline down
+        extra["delta_int64"] = {"error": repr(e)}
+    try:
+        n = 64 << 20
+        chunk, pages = pqgen.dict_chunk(0x5EED0009, n, 12, 4096, 1 << 20)
+        best = None
+        for i in range(3):
+            t0 = time.perf_counter()
+            dec.submit(chunk, pages, pq.INT32)
+            t = dec.fetch()
+            dt = time.perf_counter() - t0
+            assert t.status == 0
+            best = dt if best is None else min(best, dt)
+        extra["host_to_host"] = {"workload": "INT32 RLE_DICTIONARY w=12, %d Mi values: host bytes -> pinned staging -> H2D -> decode "
+                                             "-> D2H into pageable numpy" % (n >> 20),
+                                 "decoded_GBps": round(n * 4 / best / 1e9, 2), "ms": round(best * 1e3, 2)}
+    except Exception as e:
+        extra["host_to_host"] = {"error": repr(e)}
+    return extra
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,9 @@ __global__ void k_page_setup(ChunkCtx c) {
 // 128-bit accesses, the next window prefetched into registers while the current one is walked;
 // every lane executes the same walk on wave-uniform scalars.
 // ---------------------------------------------------------------------------------------------
+constexpr int kRunLdsBytes = ((int)sizeof(RunEntry) * (kRunSlice + 3) + 15) / 16 * 16;   // run slice + end marker
+constexpr int kSegLdsBytes = 128;                                                    // segment table
+constexpr int kStageMax = 18 * 1024;                                                 // packed bytes of one tile, at most
 constexpr int kWin = 4096;           // window bytes
 constexpr int kWinVec = kWin / 16 + 4;  // 16-byte vectors per window incl. 64 bytes look-ahead
 constexpr int kWinPerLane = (kWinVec + 63) / 64;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   const uint32_t L = (uint32_t)sp->len, avail = (uint32_t)sp->avail;
   RunEntry *runs = c.runs + sp->run_base;
   const int run_cap = sp->run_cap;
-  int32_t *tile_run = c.tile_run + sp->tile_base;
+  int2 *tile_run = reinterpret_cast<int2 *>(c.tile_run) + sp->tile_base;  // per tile: {run index, stream byte position}
 
   if (w > 32) {
     if (lane == 0) { sp->status = PQD_ERR_BIT_WIDTH; sp->n_runs = 0; }
@@ -187,129 +190,179 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   const uint32_t q_avail_end = a + avail;
   const uint32_t qend = a + L;  // L < 2^31
   const uint32_t nb_rle = (uint32_t)(w + 7) / 8;
+  const uint32_t ucnt = (uint32_t)cnt;
 
   uint32_t q = a;
-  uint32_t wq = a + 0x80000000u;   // no window yet: q - wq is huge
-  uint32_t pf_wq = 0xFFFFFFFFu;    // window held in the prefetch registers
+  uint32_t pf_wq = a + 0x80000000u; // window held in the prefetch registers (none yet: q - pf_wq is huge)
   WinRegs pf;
-  uint64_t out = 0;                // values decoded so far
+  uint64_t out = 0;                // values decoded so far (saturates the walk at 2^40)
   uint32_t emit_end = 0;
+  uint32_t emit_q = a;             // stream position (q-space) after the last emitted run
   int nr = 0;
   uint32_t ex = 0, ey = 0;         // this lane's pending run entry
   int status = PQD_OK;
 
-  // makes the window cover [qq, qq + 64)
-  auto ensure_window = [&](uint32_t qq) {
-    if (qq - wq >= (uint32_t)kWin) {
-      uint32_t nwq = qq & ~15u;
-      __syncthreads();
-      if (nwq != pf_wq) win_load(pf, base16, nwq, q_avail_end, lane);
-      win_store(pf, win4, lane);
-      wq = nwq;
-      pf_wq = wq + kWin;
-      win_load(pf, base16, pf_wq, q_avail_end, lane);  // in flight while this window is walked
-      __syncthreads();
-    }
-  };
-  // 8 bytes at qq as two wave-uniform dwords
-  auto read8 = [&](uint32_t qq, uint32_t &x0, uint32_t &x1) {
-    const uint32_t di = (qq - wq) >> 2;
-    const uint32_t sh = (qq & 3u) * 8u;
-    uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
-    uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
-    uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
-    x0 = __builtin_amdgcn_alignbit(d1, d0, sh);
-    x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
-  };
-  auto emit = [&](uint32_t x, uint32_t y) {
-    if (lane == (nr & 63)) { ex = x; ey = y; }
-    nr++;
-    if ((nr & 63) == 0) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
-  };
+  // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
+  // [wq, wq + kWin).  The next window is in flight (registers) while the current one is walked.
+  while (q < qend && status == PQD_OK) {
+    // the prefetched window when q falls inside it, else (first window, or a jump past it) a fresh one
+    const uint32_t wq = (q - pf_wq < (uint32_t)kWin) ? pf_wq : (q & ~15u);
+    if (wq != pf_wq) win_load(pf, base16, wq, q_avail_end, lane);
+    __syncthreads();
+    win_store(pf, win4, lane);
+    pf_wq = wq + kWin;
+    win_load(pf, base16, pf_wq, q_avail_end, lane);
+    __syncthreads();
 
-  while (q < qend) {
-    ensure_window(q);
-    uint32_t x0, x1;
-    read8(q, x0, x1);
-    // varint header; bytes past the end of the stream read as zero, which ends the varint with the
-    // partial value the reference returns at EOF
-    uint64_t header;
-    uint32_t hlen;
-    if ((x0 & 0x80u) == 0) { header = x0 & 0x7Fu; hlen = 1; }
-    else if ((x0 & 0x8000u) == 0) { header = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u); hlen = 2; }
-    else if ((x0 & 0x800000u) == 0) { header = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u) | ((x0 >> 2) & 0x1FC000u); hlen = 3; }
-    else if ((x0 & 0x80000000u) == 0) {
-      header = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u) | ((x0 >> 2) & 0x1FC000u) | ((x0 >> 3) & 0xFE00000u);
-      hlen = 4;
-    } else {
-      // long varint: byte by byte (the window holds 64 bytes of look-ahead)
-      header = 0;
-      uint32_t n = 0, shift = 0;
-      for (;;) {
-        uint32_t qq = q + n;
-        if (qq >= qend || n >= 60) break;
-        uint32_t b = (__builtin_amdgcn_readfirstlane(win[(qq - wq) >> 2]) >> ((qq & 3u) * 8u)) & 0xFFu;
-        n++;
-        if (shift < 64) header |= (uint64_t)(b & 0x7Fu) << shift;
-        if ((b & 0x80u) == 0) break;
-        shift += 7;
+    // Hot loop: runs with a 1- or 2-byte header that start in this window at least 12 bytes before the end of
+    // the stream, while values are still wanted.  Branch-free apart from the rare exits; everything is
+    // wave-uniform and stays on the scalar unit.  Anything else falls through to the general loop below.
+    if (w > 0) {
+      const uint32_t lim = (qend - 12u < wq + (uint32_t)kWin && qend >= 12u) ? qend - 12u : (qend >= 12u ? wq + (uint32_t)kWin : 0u);
+      const uint32_t rle_mask = nb_rle >= 4 ? 0xFFFFFFFFu : ((1u << (8u * nb_rle)) - 1u);
+      uint32_t o32 = out < (uint64_t)ucnt ? (uint32_t)out : ucnt;
+      // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
+      while (q < lim && o32 < ucnt) {
+        const uint32_t run_q = q;
+        const uint32_t di = (q - wq) >> 2;
+        const uint32_t sh = (q & 3u) * 8u;
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
+        const uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
+        const uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
+        const uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+        const uint32_t x1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+        const uint32_t two = (x0 >> 7) & 1u;
+        if (__builtin_expect((x0 & 0x8080u) == 0x8080u, 0)) break;  // header of 3 or more bytes
+        const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
+        const uint32_t hlen = 1u + two;
+        const uint32_t isbp = header & 1u;
+        const uint32_t cg = header >> 1;
+        const uint32_t nv = cg << (isbp * 3u);
+        const uint32_t nbytes = ((cg * (uint32_t)w) & (0u - isbp)) | (nb_rle & (isbp - 1u));
+        const uint32_t val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen)) & rle_mask;
+        const uint32_t bpm = 0u - isbp;  // all ones for a bit-packed run
+        const uint32_t e_y = ((q + hlen - a) & bpm) | (val & ~bpm);
+        const uint32_t e_x = (isbp << 31) | o32;
+        const uint32_t nq = q + hlen + nbytes;
+        q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
+        if (__builtin_expect(nv == 0, 0)) continue;
+        const uint32_t endv = o32 + nv;
+        const uint32_t endc = endv < ucnt ? endv : ucnt;
+        const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);
+        if (__builtin_expect(kt < endc, 0))
+          for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
+            tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
+        if (lane == (nr & 63)) { ex = e_x; ey = e_y; }
+        nr++;
+        if (__builtin_expect((nr & 63) == 0, 0)) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
+        emit_end = endv;
+        emit_q = q;
+        o32 = endv;
       }
-      q += n;
-      if (q >= qend) q = qend;
-      else { ensure_window(q); read8(q, x0, x1); }  // what follows the header, re-read at its own position
-      hlen = 0;
+      if (out < (uint64_t)ucnt) out = o32;
     }
-    q += hlen;
-    if (q > qend) q = qend;
 
-    uint32_t e_x, e_y;
-    uint64_t n_vals;
-    if ((header & 1u) == 0) {  // RLE run, encodingread.go:146-167
-      n_vals = header >> 1;
-      uint32_t val = 0;
-      if (nb_rle > 0) {
-        if (q >= qend) { status = PQD_ERR_EOF; break; }
-        // the value bytes follow the header: bytes hlen.. of (x1:x0)
-        uint64_t x = ((uint64_t)x1 << 32) | x0;
-        val = (uint32_t)(x >> (8u * hlen));
-        uint32_t have = qend - q < nb_rle ? qend - q : nb_rle;  // a short read is zero filled
-        if (have < 4) val &= (1u << (8u * have)) - 1u;
-        q += have;
+    while (q - wq < (uint32_t)kWin && q < qend) {
+      // 8 bytes at q, wave-uniform, on the scalar unit
+      const uint32_t run_q = q;
+      uint32_t di = (q - wq) >> 2;
+      const uint32_t sh = (q & 3u) * 8u;
+      uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
+      uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
+      uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
+      uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+      uint32_t x1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+      // varint header (encodingread.go:127-143).  Bytes past the end of the stream read as zero, which ends
+      // the varint with the partial value the reference returns at EOF.
+      uint32_t header, hlen;
+      if ((x0 & 0x80u) == 0) { header = x0 & 0x7Fu; hlen = 1; }
+      else if ((x0 & 0x8000u) == 0) { header = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u); hlen = 2; }
+      else {
+        // longer header: byte by byte inside the 64-byte look-ahead
+        uint64_t h64 = 0;
+        uint32_t n = 0, shift = 0;
+        for (;;) {
+          const uint32_t qq = q + n;
+          if (qq >= qend || n >= 56) break;
+          const uint32_t b = (__builtin_amdgcn_readfirstlane(win[(qq - wq) >> 2]) >> ((qq & 3u) * 8u)) & 0xFFu;
+          n++;
+          if (shift < 64) h64 |= (uint64_t)(b & 0x7Fu) << shift;
+          if ((b & 0x80u) == 0) break;
+          shift += 7;
+        }
+        if (h64 >> 31) { status = PQD_ERR_MALFORMED; break; }  // a run of >= 2^30 values: the reference runs out of memory
+        header = (uint32_t)h64;
+        hlen = n;
+        // the bytes after the header, for an RLE value
+        const uint32_t qv = q + n;
+        di = (qv - wq) >> 2;
+        const uint32_t shv = (qv & 3u) * 8u;
+        d0 = __builtin_amdgcn_readfirstlane(win[di]);
+        d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
+        x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> shv) ;
+        x1 = 0;
+        // shift so that the common code below finds the value at byte `hlen`
+        const uint64_t v64 = (uint64_t)x0;
+        x0 = 0; x1 = 0;
+        // store value bytes at byte offset hlen of (x1:x0) only when hlen <= 4; longer headers keep it aside
+        if (n <= 4) { const uint64_t t = v64 << (8u * n); x0 = (uint32_t)t; x1 = (uint32_t)(t >> 32); }
+        else { x0 = (uint32_t)v64; hlen = 0; q += n; if (q > qend) q = qend; }
       }
-      e_x = 0; e_y = val;
-    } else {  // bit-packed run, encodingread.go:170-228
-      uint64_t g = header >> 1;
-      if (g >> 40) { status = PQD_ERR_MALFORMED; break; }
-      n_vals = g * 8;
-      if (n_vals == 0) continue;
-      if (w > 0) {
-        if (q >= qend) { status = PQD_ERR_EOF; break; }
-        e_x = 0x80000000u; e_y = q - a;
-        uint64_t nbytes = g * (uint64_t)w;
-        uint64_t left = qend - q;
-        q += (uint32_t)(nbytes < left ? nbytes : left);
-      } else {
-        e_x = 0; e_y = 0;  // width 0: zeros, nothing consumed
+      const uint32_t qh = (q + hlen < qend) ? q + hlen : qend;  // position after the header
+      const uint32_t c_or_g = header >> 1;
+      uint32_t e_x, e_y, nv;
+      if ((header & 1u) == 0) {  // RLE run, encodingread.go:146-167
+        nv = c_or_g;
+        uint32_t val = 0;
+        q = qh;
+        if (nb_rle > 0) {
+          if (qh >= qend) { status = PQD_ERR_EOF; break; }   // Read at the end of the buffer
+          uint32_t have = qend - qh < nb_rle ? qend - qh : nb_rle;  // a short read is zero filled
+          val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen));
+          if (have < 4) val &= (1u << (8u * have)) - 1u;
+          q = qh + have;
+        }
+        e_x = 0; e_y = val;
+      } else {  // bit-packed run, encodingread.go:170-228
+        if (c_or_g >> 27) { status = PQD_ERR_MALFORMED; break; }
+        nv = c_or_g * 8u;
+        q = qh;
+        if (nv == 0) continue;
+        if (w > 0) {
+          if (qh >= qend) { status = PQD_ERR_EOF; break; }   // Read at the end of the buffer
+          e_x = 0x80000000u; e_y = qh - a;
+          const uint64_t nbytes = (uint64_t)c_or_g * (uint32_t)w;
+          const uint32_t left = qend - qh;
+          q = qh + (nbytes < (uint64_t)left ? (uint32_t)nbytes : left);  // a payload cut short is zero filled
+        } else {
+          e_x = 0; e_y = 0;  // width 0: zeros, nothing consumed
+        }
       }
+      if (nv == 0) continue;
+      if (out < (uint64_t)ucnt) {
+        if (nr >= run_cap - 1) { status = PQD_ERR_NOMEM; break; }
+        const uint32_t start = (uint32_t)out;
+        const uint64_t e64 = out + nv;
+        const uint32_t endc = e64 < (uint64_t)ucnt ? (uint32_t)e64 : ucnt;
+        // tiles whose first value lies in this run
+        const uint32_t kt = (start + kTile - 1) & ~(uint32_t)(kTile - 1);
+        if (kt < endc)
+          for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
+            tile_run[k] = make_int2(nr, (int)((e_x >> 31) ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - start) * (uint32_t)w) >> 3) : run_q - a));
+        if (lane == (nr & 63)) { ex = e_x | start; ey = e_y; }
+        nr++;
+        if ((nr & 63) == 0) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
+        emit_end = e64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)e64;
+        emit_q = q;
+      }
+      out += nv;
     }
-    if (n_vals >> 40) { status = PQD_ERR_MALFORMED; break; }
-    if (n_vals == 0) continue;
-    if (out < (uint64_t)cnt) {
-      if (nr >= run_cap - 1) { status = PQD_ERR_NOMEM; break; }
-      const uint32_t start = (uint32_t)out;
-      uint64_t endv = out + n_vals;
-      if (endv > (uint64_t)cnt) endv = (uint64_t)cnt;
-      // tiles whose first value lies in this run
-      for (uint32_t k = (start + kTile - 1) / kTile + lane; (uint64_t)k * kTile < endv; k += 64) tile_run[k] = nr;
-      emit(e_x | start, e_y);
-      uint64_t e = out + n_vals;
-      emit_end = e > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)e;
-    }
-    out += n_vals;
   }
   // end sentinel, then flush the partial group
   const int n_runs = nr;
-  emit(emit_end, 0);
+  if (lane == (nr & 63)) { ex = emit_end; ey = 0; }
+  nr++;
+  if ((nr & 63) == 0) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
   {
     int pending = nr & 63;
     if (lane < pending) { runs[nr - pending + lane].x = ex; runs[nr - pending + lane].y = ey; }
@@ -317,6 +370,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   if (status == PQD_OK && out < (uint64_t)cnt) status = PQD_ERR_MALFORMED;  // buf[:cnt] past the decoded values
   if (lane == 0) {
     sp->n_runs = n_runs;
+    sp->pad = (int32_t)(emit_q - a);  // end of the bytes the emitted runs occupy
     sp->decoded = (int64_t)out;
     if (status != PQD_OK) sp->status = status;
   }
@@ -402,6 +456,7 @@ __device__ __forceinline__ void decode4(RunPtr R, int nr, int v, int n4, const u
 struct ExpandArgs {
   ChunkCtx c;
   const int32_t *tile_prefix;  // n_streams + 1 entries
+  const int32_t *tile_stream;  // n_tiles entries: stream (relative to stream0) of each tile
   int n_streams;
   int stream0;
   int n_tiles;
@@ -409,71 +464,190 @@ struct ExpandArgs {
   const uint8_t *dict;         // dictionary, elem_size bytes per entry, 16-byte aligned and padded
   int32_t dict_n;
   int32_t dict_lds;            // stage the dictionary in LDS
+  int32_t stage_bytes;         // LDS bytes for the packed bytes of one tile (multiple of 16)
   uint8_t *values_out;
+};
+
+// Values v .. v+n4-1 of a stream given the run index i of the run holding v (general path: straight from
+// global memory, any number of runs).
+template <class RunPtr>
+__device__ __forceinline__ void decode4_at(RunPtr R, int i, int v, int n4, const uint8_t *sbase, uint32_t avail, int w,
+                                           uint32_t out[4]) {
+  uint32_t ex = R[i].x, ey = R[i].y;
+  int start = (int)(ex & 0x7FFFFFFFu);
+  int next = (int)(R[i + 1].x & 0x7FFFFFFFu);
+  for (int j = 0; j < n4; j++) {
+    const int vv = v + j;
+    while (vv >= next) {
+      i++;
+      ex = R[i].x; ey = R[i].y;
+      start = (int)(ex & 0x7FFFFFFFu);
+      next = (int)(R[i + 1].x & 0x7FFFFFFFu);
+    }
+    if ((ex >> 31) == 0) out[j] = ey;
+    else out[j] = extract_bits(sbase, avail, ey, (uint64_t)(uint32_t)(vv - start) * (uint32_t)w, w);
+  }
+}
+
+struct TileCtx {
+  int t0, t1, nr, w, page;
+  uint32_t avail;
+  const uint8_t *sbase;
+  int64_t out_base;
+  bool in_lds, is_def;
+  int org;  // stream position of the first staged byte (may be slightly negative)
 };
 
 // MODE 0: levels -> int32 (+ counts); MODE 4 / 8: dictionary gather of 4- / 8-byte elements;
 // MODE 1: dictionary gather of elem_size-byte elements (BOOLEAN, INT96, FIXED_LEN_BYTE_ARRAY)
-template <int MODE>
+//
+// Per tile: the run slice and the packed bytes the tile needs are staged in LDS with coalesced 128-bit loads
+// (every input byte is read from HBM once); each lane then decodes four consecutive values: a branch-free
+// binary search over the runs of its wave's 256-value segment, two-dword LDS reads per value, funnel shift,
+// mask, dictionary lookup, one 16-byte store.  A wave's stores cover 1 KiB of contiguous output.
+template <int MODE, bool DICT_LDS>
 __global__ __launch_bounds__(256) void k_hybrid_expand(ExpandArgs a) {
   extern __shared__ uint4 smem[];
   RunEntry *s_runs = reinterpret_cast<RunEntry *>(smem);
-  uint8_t *s_dict = reinterpret_cast<uint8_t *>(smem) + sizeof(RunEntry) * (kRunSlice + 2);
+  int *s_seg = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes);  // kTile / 256 + 1 entries
+  uint32_t *s_stage = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes);
+  const uint8_t *s_dict = reinterpret_cast<const uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
   const int tid = threadIdx.x;
   const ChunkCtx &c = a.c;
   const int esz = c.elem_size;
 
-  if (MODE != 0 && a.dict_lds) {
+  if (MODE != 0 && DICT_LDS) {
     const int nvec = (a.dict_n * esz + 15) / 16;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.dict);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_dict);
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes + a.stage_bytes);
     for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
   }
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    int lo = 0, hi = a.n_streams;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (a.tile_prefix[mid] <= tile) lo = mid; else hi = mid;
-    }
-    const int k = tile - a.tile_prefix[lo];
-    const Stream *sp = &c.streams[a.stream0 + lo];
+    const int ls = a.tile_stream[tile];
+    const int k = tile - a.tile_prefix[ls];
+    const Stream *sp = &c.streams[a.stream0 + ls];
     const int cnt = sp->cnt;
-    const int t0 = k * kTile;
-    if (sp->status != 0 || t0 >= cnt) continue;
-    const int t1 = cnt < t0 + kTile ? cnt : t0 + kTile;
-    const int32_t *tile_run = c.tile_run + sp->tile_base;
-    const int r0 = tile_run[k];
-    const int r1 = (t0 + kTile < cnt) ? tile_run[k + 1] : sp->n_runs - 1;
-    const int nr = r1 - r0 + 2;
+    TileCtx t;
+    t.t0 = k * kTile;
+    if (sp->status != 0 || t.t0 >= cnt) continue;
+    t.t1 = cnt < t.t0 + kTile ? cnt : t.t0 + kTile;
+    const int2 *tile_run = reinterpret_cast<const int2 *>(c.tile_run) + sp->tile_base;
+    const int2 tk = tile_run[k];
+    const bool last_tile = !(t.t0 + kTile < cnt);
+    const int2 tk1 = last_tile ? make_int2(sp->n_runs - 1, sp->pad) : tile_run[k + 1];
+    const int r0 = tk.x, r1 = tk1.x;
+    t.nr = r1 - r0 + 2;
     const RunEntry *gruns = c.runs + sp->run_base + r0;
-    const bool in_lds = nr <= kRunSlice + 2;
-    const uint8_t *sbase = c.in + sp->off;
-    const uint32_t avail = (uint32_t)sp->avail;
-    const int w = sp->w;
-    const int64_t out_base = sp->out_base;
-    const int page = sp->page;
+    t.sbase = c.in + sp->off;
+    t.avail = (uint32_t)sp->avail;
+    t.w = sp->w;
+    t.out_base = sp->out_base;
+    t.page = sp->page;
+    t.is_def = (a.stream0 + ls) >= c.nd;
+    const uint32_t w = (uint32_t)t.w;
+    const uint32_t mask = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    // stream bytes the tile can touch: from the position of its first value to the position of the next tile's
+    // first value (or the end of the last run) plus the reach of one value; org is 16-byte aligned in memory
+    const int b_lo = tk.y;
+    const int b_hi = tk1.y + (int)((w + 7) >> 3) + 1;
+    t.org = b_lo - (int)((reinterpret_cast<uintptr_t>(t.sbase) + (uintptr_t)(uint32_t)b_lo) & 15u);
+    const int span = b_hi - t.org;
+    t.in_lds = t.nr <= kRunSlice + 2 && span + 8 <= a.stage_bytes;
 
-    __syncthreads();
-    if (in_lds) for (int i = tid; i < nr; i += 256) s_runs[i] = gruns[i];
-    __syncthreads();
+    __syncthreads();  // the previous tile is done with LDS
+    if (t.in_lds) {
+      // run slice, segment table and packed bytes: all loads issued before the one barrier
+      for (int i = tid; i < t.nr; i += 256) {
+        const RunEntry e = gruns[i];
+        s_runs[i] = e;
+        if (i < t.nr - 1) {
+          // the 256-value segments whose first value run i holds
+          const int st = (int)(e.x & 0x7FFFFFFFu), nx = (int)(gruns[i + 1].x & 0x7FFFFFFFu);
+          int j = st <= t.t0 ? 0 : (st - t.t0 + 255) >> 8;
+          for (; j <= kTile / 256 && t.t0 + j * 256 < nx; j++) s_seg[j] = i;
+        } else {
+          // i is the end marker: segments at or beyond the end of the last run
+          const int last_end = (int)(e.x & 0x7FFFFFFFu);
+          int j = last_end <= t.t0 ? 0 : (last_end - t.t0 + 255) >> 8;
+          for (; j <= kTile / 256; j++) s_seg[j] = t.nr - 2;
+        }
+      }
+      if (tid == 0) { s_runs[t.nr].x = 0x7FFFFFFFu; s_runs[t.nr].y = 0; }
+      const int nvec = (span + 8 + 15) >> 4;
+      for (int i = tid; i < nvec; i += 256) {
+        const int sp0 = t.org + 16 * i;  // stream position of this vector
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (sp0 < (int)t.avail) {
+          x = *reinterpret_cast<const uint4 *>(t.sbase + sp0);
+          const int left = (int)t.avail - sp0;
+          if (left < 16) {
+            uint32_t wv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int lb = left - 4 * q;
+              if (lb <= 0) wv[q] = 0;
+              else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
+            }
+            x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+          }
+        }
+        reinterpret_cast<uint4 *>(s_stage)[i] = x;
+      }
+      __syncthreads();
+    }
 
     int n_flag = 0;  // levels: nulls or rows counted by this thread
     bool bad_index = false;
-#pragma unroll 1
+#pragma unroll
     for (int it = 0; it < kTile / 1024; it++) {
-      const int v = t0 + it * 1024 + tid * 4;
-      if (v >= t1) continue;
-      const int n4 = t1 - v < 4 ? t1 - v : 4;
+      const int rel = it * 1024 + tid * 4;
+      const int v = t.t0 + rel;
+      if (v >= t.t1) continue;
+      const int n4 = t.t1 - v < 4 ? t.t1 - v : 4;
       uint32_t x[4] = {0, 0, 0, 0};
-      if (in_lds) decode4(s_runs, nr, v, n4, sbase, avail, w, x);
-      else decode4(gruns, nr, v, n4, sbase, avail, w, x);
+      if (t.in_lds) {
+        // branch-free search of the run holding v among the runs of this wave's segment (uniform bounds)
+        const int seg = rel >> 8;
+        const int s_lo = __builtin_amdgcn_readfirstlane(s_seg[seg]);
+        const int s_hi = __builtin_amdgcn_readfirstlane(s_seg[seg + 1]);
+        int lo = s_lo, up = s_hi + 1;
+        for (int span = s_hi - s_lo; span > 0; span >>= 1) {
+          const int mid = (lo + up) >> 1;
+          const bool le = (int)(s_runs[mid].x & 0x7FFFFFFFu) <= v;
+          lo = le ? mid : lo;
+          up = le ? up : mid;
+        }
+        const int i = lo;
+        const uint32_t exA = s_runs[i].x, eyA = s_runs[i].y, exB = s_runs[i + 1].x, eyB = s_runs[i + 1].y;
+        const int startA = (int)(exA & 0x7FFFFFFFu), nextA = (int)(exB & 0x7FFFFFFFu);
+        const int nextB = (int)(s_runs[i + 2].x & 0x7FFFFFFFu);
+        if (v + n4 > nextB) {
+          // three or more runs within four values
+          decode4_at(s_runs, i, v, n4, t.sbase, t.avail, t.w, x);
+        } else {
+          const bool bpA = exA >> 31, bpB = exB >> 31;
+          // bit position in the staging buffer of value v of run A / run B (mod 2^32; the true value is small)
+          const uint32_t baseA = ((eyA - (uint32_t)t.org) << 3) + (uint32_t)(v - startA) * w;
+          const uint32_t baseB = ((eyB - (uint32_t)t.org) << 3) + (uint32_t)(v - nextA) * w;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool inA = v + j < nextA;
+            const bool bp = inA ? bpA : bpB;
+            const uint32_t P = bp ? (inA ? baseA : baseB) + (uint32_t)j * w : 0u;
+            const uint32_t d0 = s_stage[P >> 5], d1 = s_stage[(P >> 5) + 1];
+            const uint32_t bits = __builtin_amdgcn_alignbit(d1, d0, P & 31u) & mask;
+            x[j] = bp ? bits : (inA ? eyA : eyB);
+          }
+        }
+      } else {
+        decode4(gruns, t.nr, v, n4, t.sbase, t.avail, t.w, x);
+      }
 
       if (MODE == 0) {
-        const bool is_def = (a.stream0 + lo) >= c.nd;
-        int32_t *outp = (is_def ? a.def_out : a.rep_out) + out_base + v;
-        const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
-        for (int j = 0; j < n4; j++) n_flag += is_def ? (x[j] != cmp) : (x[j] == cmp);
+        int32_t *outp = (t.is_def ? a.def_out : a.rep_out) + t.out_base + v;
+        const uint32_t cmp = t.is_def ? (uint32_t)c.max_def : 0u;
+        for (int j = 0; j < n4; j++) n_flag += t.is_def ? (x[j] != cmp) : (x[j] == cmp);
         if (n4 == 4) {
           U32x4Unaligned o = {{x[0], x[1], x[2], x[3]}};
           *reinterpret_cast<U32x4Unaligned *>(outp) = o;
@@ -482,14 +656,15 @@ __global__ __launch_bounds__(256) void k_hybrid_expand(ExpandArgs a) {
         }
       } else if (MODE == 4) {
         uint32_t y[4];
+#pragma unroll
         for (int j = 0; j < 4; j++) {
           uint32_t idx = x[j];
-          if (j < n4 && idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-          if (j >= n4) idx = 0;
-          y[j] = a.dict_lds ? reinterpret_cast<const uint32_t *>(s_dict)[idx]
-                            : reinterpret_cast<const uint32_t *>(a.dict)[idx];
+          if (idx >= (uint32_t)a.dict_n) { bad_index = bad_index || (j < n4); idx = 0; }
+          // (kept as two code paths: a run-time choice of address space would turn every lookup into a flat load)
+          if (DICT_LDS) y[j] = reinterpret_cast<const uint32_t *>(s_dict)[idx];
+          else y[j] = reinterpret_cast<const uint32_t *>(a.dict)[idx];
         }
-        uint32_t *outp = reinterpret_cast<uint32_t *>(a.values_out) + out_base + v;
+        uint32_t *outp = reinterpret_cast<uint32_t *>(a.values_out) + t.out_base + v;
         if (n4 == 4) {
           U32x4Unaligned o = {{y[0], y[1], y[2], y[3]}};
           *reinterpret_cast<U32x4Unaligned *>(outp) = o;
@@ -498,14 +673,14 @@ __global__ __launch_bounds__(256) void k_hybrid_expand(ExpandArgs a) {
         }
       } else if (MODE == 8) {
         uint64_t y[4];
+#pragma unroll
         for (int j = 0; j < 4; j++) {
           uint32_t idx = x[j];
-          if (j < n4 && idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-          if (j >= n4) idx = 0;
-          y[j] = a.dict_lds ? reinterpret_cast<const uint64_t *>(s_dict)[idx]
-                            : reinterpret_cast<const uint64_t *>(a.dict)[idx];
+          if (idx >= (uint32_t)a.dict_n) { bad_index = bad_index || (j < n4); idx = 0; }
+          if (DICT_LDS) y[j] = reinterpret_cast<const uint64_t *>(s_dict)[idx];
+          else y[j] = reinterpret_cast<const uint64_t *>(a.dict)[idx];
         }
-        uint64_t *outp = reinterpret_cast<uint64_t *>(a.values_out) + out_base + v;
+        uint64_t *outp = reinterpret_cast<uint64_t *>(a.values_out) + t.out_base + v;
         if (n4 == 4) {
           U64x2Unaligned o0 = {{y[0], y[1]}}, o1 = {{y[2], y[3]}};
           reinterpret_cast<U64x2Unaligned *>(outp)[0] = o0;
@@ -517,21 +692,19 @@ __global__ __launch_bounds__(256) void k_hybrid_expand(ExpandArgs a) {
         for (int j = 0; j < n4; j++) {
           uint32_t idx = x[j];
           if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-          const uint8_t *src = (a.dict_lds ? s_dict : a.dict) + (size_t)idx * esz;
-          uint8_t *dst = a.values_out + (size_t)(out_base + v + j) * esz;
-          for (int b = 0; b < esz; b++) dst[b] = src[b];
+          uint8_t *dst = a.values_out + (size_t)(t.out_base + v + j) * esz;
+          if (DICT_LDS) { const uint8_t *src = s_dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
+          else { const uint8_t *src = a.dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
         }
       }
     }
+
     if (MODE == 0) {
       // wave reduction, one atomic per wave
       for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
-      if ((tid & 63) == 0 && n_flag) {
-        const bool is_def = (a.stream0 + lo) >= c.nd;
-        atomicAdd(is_def ? &c.state[page].n_nulls : &c.state[page].n_rows, n_flag);
-      }
+      if ((tid & 63) == 0 && n_flag) atomicAdd(t.is_def ? &c.state[t.page].n_nulls : &c.state[t.page].n_rows, n_flag);
     } else {
-      if (bad_index) set_status(&c.state[page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
+      if (bad_index) set_status(&c.state[t.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
     }
   }
 }
@@ -660,15 +833,23 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, int32_t *rep_out,
-                                int32_t *def_out, hipStream_t stream) {
+static int clamp_stage(int stage_bytes) {
+  int sb = (stage_bytes + 15) / 16 * 16;
+  if (sb < 1024) sb = 1024;
+  if (sb > kStageMax) sb = kStageMax;
+  return sb;
+}
+
+hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+                                int stage_bytes, int32_t *rep_out, int32_t *def_out, hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.n_streams = 2 * c.nd; a.stream0 = 0; a.n_tiles = n_tiles;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.n_streams = 2 * c.nd; a.stream0 = 0; a.n_tiles = n_tiles;
   a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.dict_lds = 0; a.values_out = nullptr;
+  a.stage_bytes = clamp_stage(stage_bytes);
   int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
-  size_t shmem = sizeof(RunEntry) * (kRunSlice + 2);
-  hipLaunchKernelGGL(k_hybrid_expand<0>, dim3(grid), dim3(256), shmem, stream, a);
+  size_t shmem = kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
+  hipLaunchKernelGGL((k_hybrid_expand<0, false>), dim3(grid), dim3(256), shmem, stream, a);
   return hipGetLastError();
 }
 
@@ -682,38 +863,36 @@ hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, const uint8_t *dict,
-                              int32_t dict_n, uint8_t *values_out, int n_cu, hipStream_t stream) {
+hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+                              int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, int n_cu,
+                              hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.n_streams = c.nd; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.n_streams = c.nd; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
   a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out;
-  const size_t run_bytes = sizeof(RunEntry) * (kRunSlice + 2);
+  a.stage_bytes = clamp_stage(stage_bytes);
+  const size_t run_bytes = kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
   const size_t dict_bytes = ((size_t)dict_n * c.elem_size + 15) / 16 * 16;
   // dictionaries up to 48 KiB are staged in LDS (three 256-thread blocks per CU keep 160 KiB of LDS busy);
   // larger ones are gathered from L2 / HBM
   a.dict_lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;
   size_t shmem = run_bytes + (a.dict_lds ? dict_bytes : 0);
-  int per_cu = a.dict_lds ? (int)(160 * 1024 / (shmem + 512)) : 8;
+  int per_cu = (int)(160 * 1024 / (shmem + 512));
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   int grid = n_cu * per_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipError_t e = hipSuccess;
-  if (c.elem_size == 4) {
-    if (shmem > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hybrid_expand<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hybrid_expand<4>, dim3(grid), dim3(256), shmem, stream, a);
-  } else if (c.elem_size == 8) {
-    if (shmem > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hybrid_expand<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hybrid_expand<8>, dim3(grid), dim3(256), shmem, stream, a);
-  } else {
-    if (shmem > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hybrid_expand<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hybrid_expand<1>, dim3(grid), dim3(256), shmem, stream, a);
-  }
-  return hipGetLastError();
+  auto go = [&](auto kern) -> hipError_t {
+    if (shmem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, a);
+    return hipGetLastError();
+  };
+  if (c.elem_size == 4) return a.dict_lds ? go(&k_hybrid_expand<4, true>) : go(&k_hybrid_expand<4, false>);
+  if (c.elem_size == 8) return a.dict_lds ? go(&k_hybrid_expand<8, true>) : go(&k_hybrid_expand<8, false>);
+  return a.dict_lds ? go(&k_hybrid_expand<1, true>) : go(&k_hybrid_expand<1, false>);
 }
 
 }  // namespace pqd

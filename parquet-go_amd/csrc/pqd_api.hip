@@ -229,7 +229,15 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   const size_t off_tp_lv = align_up(off_streams + sizeof(Stream) * n_streams, 256);
   const size_t off_tp_dc = align_up(off_tp_lv + 4 * tp_levels.size(), 256);
   const size_t off_tp_pl = align_up(off_tp_dc + 4 * tp_dict.size(), 256);
-  const size_t meta_bytes = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
+  // tile -> stream maps of the two hybrid expansions
+  std::vector<int32_t> ts_levels((size_t)tp_levels.back()), ts_dict((size_t)tp_dict.back());
+  for (size_t i = 0; i + 1 < tp_levels.size(); i++)
+    for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_levels[(size_t)t] = (int32_t)i;
+  for (size_t i = 0; i + 1 < tp_dict.size(); i++)
+    for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dict[(size_t)t] = (int32_t)i;
+  const size_t off_ts_lv = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
+  const size_t off_ts_dc = align_up(off_ts_lv + 4 * ts_levels.size(), 256);
+  const size_t meta_bytes = align_up(off_ts_dc + 4 * ts_dict.size(), 256);
   int rc;
   if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(meta_bytes))) return rc;
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
@@ -241,12 +249,14 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
     std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
     std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
+    if (!ts_levels.empty()) std::memcpy(m + off_ts_lv, ts_levels.data(), 4 * ts_levels.size());
+    if (!ts_dict.empty()) std::memcpy(m + off_ts_dc, ts_dict.data(), 4 * ts_dict.size());
   }
   HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, meta_bytes, hipMemcpyHostToDevice, h->stream));
 
   // ---- workspaces and outputs ----
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
-  if ((rc = h->tile_run.ensure(4 * (size_t)(tile_total + 64)))) return rc;
+  if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
   const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
   if ((rc = h->values.ensure(val_bytes))) return rc;
   const bool nullable = col->max_def > 0;
@@ -275,9 +285,29 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   const int32_t *d_tp_lv = reinterpret_cast<const int32_t *>(mb + off_tp_lv);
   const int32_t *d_tp_dc = reinterpret_cast<const int32_t *>(mb + off_tp_dc);
   const int32_t *d_tp_pl = reinterpret_cast<const int32_t *>(mb + off_tp_pl);
+  const int32_t *d_ts_lv = reinterpret_cast<const int32_t *>(mb + off_ts_lv);
+  const int32_t *d_ts_dc = reinterpret_cast<const int32_t *>(mb + off_ts_dc);
   int64_t *d_totals = static_cast<int64_t *>(h->small.p);
 
   uint8_t *dense_out = static_cast<uint8_t *>(nullable ? h->dense.p : h->values.p);
+
+  // LDS reserved per tile for packed bytes.  Levels: the width is known here.  Dictionary indices: the width is
+  // inside the page, so size it from the densest page's bytes per value (a tile that needs more still decodes,
+  // on a slower path); nullable columns spend their page bytes on fewer values, so they get the maximum.
+  auto bit_len = [](int x) { int n = 0; while (x) { n++; x >>= 1; } return n; };
+  const int w_lv = std::max(bit_len(col->max_def), bit_len(col->max_rep));
+  const int stage_levels = kTile * w_lv / 8 + kTile / 4 + 64;
+  int stage_dict = 18 * 1024;
+  if (!nullable) {
+    double bpv = 0.0;
+    for (int p = 0; p < n_pages; p++) {
+      const PageIn &pi = h->h_pages[(size_t)p];
+      if (pi.data_idx >= 0 && is_dict_enc(pi.encoding) && pi.num_values >= kTile)
+        bpv = std::max(bpv, (double)pi.body_len / (double)pi.num_values);
+      else if (pi.data_idx >= 0 && is_dict_enc(pi.encoding)) bpv = std::max(bpv, 4.25);
+    }
+    stage_dict = (int)(bpv * kTile * 1.25) + 512;
+  }
 
   // ---- kernels ----
   if (n_pages > 0) {
@@ -285,7 +315,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
       { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
-        HIP_TRY(launch_expand_levels(c, d_tp_lv, tp_levels.back(), static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
+        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
@@ -302,7 +332,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     else {
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<dict>");
-        HIP_TRY(launch_expand_dict(c, d_tp_dc, tp_dict.back(), static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->n_cu, h->stream)); }
+        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->n_cu, h->stream)); }
     }
   }
   if (any_plain) {
@@ -529,9 +559,9 @@ int pqd_debug_dump(pqd_handle *h) {
   }
   for (size_t i = 0; i < ss.size(); i++) {
     const Stream &x = ss[i];
-    std::fprintf(stderr, "stream %zu (group %zu) off %lld len %d avail %d w %d cnt %d out_base %lld run_base %lld cap %d tile_base %d page %d | n_runs %d status %d decoded %lld\n",
+    std::fprintf(stderr, "stream %zu (group %zu) off %lld len %d avail %d w %d cnt %d out_base %lld run_base %lld cap %d tile_base %d page %d | n_runs %d status %d decoded %lld pad %d\n",
                  i, h->nd ? i / (size_t)h->nd : 0, (long long)x.off, x.len, x.avail, x.w, x.cnt, (long long)x.out_base, (long long)x.run_base,
-                 x.run_cap, x.tile_base, x.page, x.n_runs, x.status, (long long)x.decoded);
+                 x.run_cap, x.tile_base, x.page, x.n_runs, x.status, (long long)x.decoded, x.pad);
   }
   return PQD_OK;
 }
