@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--page-values", type=int, default=1 << 20)
     ap.add_argument("--widths", type=str, default="1,2,4,8,12,16,20")
     ap.add_argument("--cpu-pages", type=int, default=24, help="pages per width decoded by the CPU oracle (baseline sample)")
+    ap.add_argument("--handles", type=int, default=7, help="chunks in flight (one handle / HIP stream each)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the DELTA_BINARY_PACKED / host-to-host extras")
     ap.add_argument("--delta-values", type=int, default=512 << 20)
@@ -72,20 +73,38 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
-    dec = pq.Decoder(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=True)
+    # One handle (= one HIP stream + workspaces) per chunk in flight, as the reference runs one goroutine per column
+    # (reader/reader.go:306-327): the serial run-header walk of one chunk overlaps the expansion of the others.
+    n_handles = max(1, min(args.handles, len(widths)))
+    decs = [pq.Decoder(local_rank, profiling=True) for _ in range(n_handles)]
+    dec = decs[0]
     ktimes = {}
 
-    def decode(item, collect=False):
-        dec.submit_device(item["dev"].data_ptr(), item["nbytes"], item["pages"], pq.INT32)
-        r = dec.wait()
+    def submit(item, d):
+        d.submit_device(item["dev"].data_ptr(), item["nbytes"], item["pages"], pq.INT32)
+
+    def finish(item, d, collect=False):
+        r = d.wait()
         if r.status != 0:
             raise RuntimeError("decode failed: status %d at page %d (w=%d)" % (r.status, r.bad_page, item["w"]))
         if collect:
-            for name, (ms, n) in dec.kernel_times().items():
+            for name, (ms, n) in d.kernel_times().items():
                 e = ktimes.setdefault((item["w"], name), [0.0, 0])
                 e[0] += ms
                 e[1] += n
         return r
+
+    def decode(item, collect=False):
+        submit(item, dec)
+        return finish(item, dec, collect)
+
+    def step(collect=False):
+        for g in range(0, len(work), n_handles):
+            group = work[g:g + n_handles]
+            for item, d in zip(group, decs):
+                submit(item, d)
+            for item, d in zip(group, decs):
+                finish(item, d, collect)
 
     # ---- verification against the CPU oracle (untimed) + CPU baseline on a bounded sample ----
     cpu = None
@@ -119,13 +138,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        for item in work:
-            decode(item)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        for item in work:
-            decode(item, collect=True)
+        step(collect=True)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -178,6 +195,7 @@ def main():
                                    "~90%% bit-packed / ~10%% RLE runs; input and output resident in HBM"
                                    % (n_values >> 20, widths, page_values >> 10),
                        "values_per_gpu": n_values, "page_values": page_values, "widths": widths,
+                       "chunks_in_flight": n_handles,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,

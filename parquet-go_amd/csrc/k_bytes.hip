@@ -1,0 +1,415 @@
+// BYTE_ARRAY columns on gfx950: PLAIN length chains, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY (prefix
+// chains), output offsets and the byte copies.
+//
+// Reference behaviour reproduced here: encoding/encodingread.go:98-112 (PLAIN BYTE_ARRAY), :385-409
+// (DELTA_LENGTH_BYTE_ARRAY), :411-435 (DELTA_BYTE_ARRAY), layout/page.go:684-706 (values[:cnt]).
+//
+// Every non-null value is first described by a 64-bit "pair": bits 0..39 = chunk offset of its bytes,
+// bits 40..63 = length (strings of 16 MiB or more are rejected).  A chunk-wide exclusive scan of the lengths
+// gives the output offsets; the copies follow.
+#include <hip/hip_runtime.h>
+#include "pqd_kernels.h"
+
+namespace pqd {
+
+constexpr uint64_t kSrcMask = (1ull << 40) - 1;
+constexpr int kMaxStrLen = (1 << 24) - 1;
+
+__device__ __forceinline__ void set_status_b(int32_t *p, int code) { atomicCAS(p, 0, code); }
+__device__ __forceinline__ uint64_t make_pair(int64_t src, int64_t len) { return ((uint64_t)len << 40) | ((uint64_t)src & kSrcMask); }
+
+// ---------------------------------------------------------------------------------------------
+// PLAIN BYTE_ARRAY: [u32 length][bytes] ... — a serial chain per page; one thread walks one page.
+// which = -1: every PLAIN data page (pairs -> pairs_out[dense_base + i]); else the dictionary page `which`
+// (pairs -> pairs_out[i]).
+// Reference semantics (encodingread.go:98-112): the 4-byte length is read leniently (zero filled when cut),
+// io.EOF only when a value starts exactly at the end.  A string that runs past the page would be zero
+// padded by the reference; here it fails the page as malformed.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
+  int p;
+  int64_t cnt, pos, end;
+  uint64_t *out;
+  if (which >= 0) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    p = which;
+    const PageIn pi = c.pages[p];
+    cnt = pi.num_values;
+    pos = pi.body_off;
+    end = pi.body_off + pi.body_len;
+    out = pairs_out;
+  } else {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= c.nd) return;
+    p = c.streams[2 * c.nd + d].page;
+    if (c.pages[p].encoding != PQD_ENC_PLAIN) return;
+    const PageState ps = c.state[p];
+    if (ps.status != 0) return;
+    cnt = ps.cnt;
+    pos = ps.val_off;
+    end = ps.val_off + ps.val_len;
+    out = pairs_out + ps.dense_base;
+  }
+  int status = PQD_OK;
+  if (cnt < 0) status = PQD_ERR_MALFORMED;
+  for (int64_t i = 0; i < cnt && status == PQD_OK; i++) {
+    if (pos >= end) { status = PQD_ERR_EOF; break; }
+    uint32_t ln = 0;
+    for (int k = 0; k < 4; k++)
+      if (pos + k < end) ln |= (uint32_t)c.in[pos + k] << (8 * k);
+    pos = pos + 4 < end ? pos + 4 : end;
+    if ((int64_t)ln > end - pos || ln > (uint32_t)kMaxStrLen) { status = PQD_ERR_MALFORMED; break; }
+    out[i] = make_pair(pos, ln);
+    pos += ln;
+  }
+  if (status != PQD_OK) set_status_b(&c.state[p].status, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DELTA_LENGTH_BYTE_ARRAY / the suffix half of DELTA_BYTE_ARRAY: lengths (already delta-decoded into
+// lens[dense_base + i]) -> pairs; the bytes of value i start where value i-1 ended, the first at the end of
+// the length stream (PageState.aux0).  One block per data page, running carry.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *lens, uint64_t *pairs_out) {
+  __shared__ int64_t s_scan[256];
+  __shared__ int64_t s_carry;
+  __shared__ int s_bad;
+  const int d = blockIdx.x, tid = threadIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != encoding) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t cnt = ps->cnt, base = ps->dense_base;
+  const int64_t end = ps->val_off + ps->val_len;
+  if (tid == 0) { s_carry = ps->aux0; s_bad = 0; }
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < cnt; i0 += 256) {
+    const int64_t i = i0 + tid;
+    int64_t ln = i < cnt ? lens[base + i] : 0;
+    if (ln < 0 || ln > kMaxStrLen) { s_bad = 1; ln = 0; }  // negative: make([]byte, huge) panics in the reference
+    s_scan[tid] = ln;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int64_t t = tid >= o ? s_scan[tid - o] : 0;
+      __syncthreads();
+      s_scan[tid] += t;
+      __syncthreads();
+    }
+    const int64_t src = s_carry + s_scan[tid] - ln;
+    if (i < cnt) {
+      if (ln > 0 && src + ln > end) s_bad = 1;  // the reference would zero pad a cut string (or hit EOF)
+      pairs_out[base + i] = make_pair(src, ln);
+    }
+    __syncthreads();
+    if (tid == 255) s_carry += s_scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
+    ps->aux1 = s_carry;  // end of the payload
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk-wide exclusive scan of the value lengths -> dense output offsets (n + 1 entries).
+// len(i) = pair length (+ prefix length for DELTA_BYTE_ARRAY pages; the first value of a page has none,
+// encodingread.go:427).
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanTile = 2048;
+
+struct LenSrc {
+  const uint64_t *pairs;
+  const int64_t *prefix;     // DELTA_BYTE_ARRAY prefix lengths (dense), or nullptr
+  const int32_t *page_of;    // unused
+};
+
+__device__ __forceinline__ int64_t value_len(const uint64_t *pairs, const int64_t *prefix, int64_t i) {
+  int64_t ln = (int64_t)(pairs[i] >> 40);
+  if (prefix) ln += prefix[i];
+  return ln;
+}
+
+__global__ __launch_bounds__(256) void k_len_tile_sums(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial) {
+  __shared__ int64_t s_w[4];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  int64_t sum = 0;
+  for (int k = threadIdx.x; k < kScanTile; k += 256) {
+    const int64_t i = base + k;
+    if (i < n) sum += value_len(pairs, prefix, i);
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of the tile sums in place; total -> partial[n_tiles]
+__global__ __launch_bounds__(1024) void k_scan_partials(int64_t *partial, int n_tiles) {
+  __shared__ int64_t s[1024];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    const int64_t x = t < n_tiles ? partial[t] : 0;
+    s[threadIdx.x] = x;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int64_t y = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (t < n_tiles) partial[t] = carry + s[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, const int64_t *partial,
+                                                     int n_tiles, int64_t *doff) {
+  __shared__ int64_t s_scan[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  const int tid = threadIdx.x;
+  // thread handles kScanTile / 256 consecutive values
+  constexpr int PER = kScanTile / 256;
+  int64_t ln[PER], sum = 0;
+  for (int k = 0; k < PER; k++) {
+    const int64_t i = base + (int64_t)tid * PER + k;
+    ln[k] = i < n ? value_len(pairs, prefix, i) : 0;
+    sum += ln[k];
+  }
+  s_scan[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    int64_t t = tid >= o ? s_scan[tid - o] : 0;
+    __syncthreads();
+    s_scan[tid] += t;
+    __syncthreads();
+  }
+  int64_t off = partial[blockIdx.x] + s_scan[tid] - sum;
+  for (int k = 0; k < PER; k++) {
+    const int64_t i = base + (int64_t)tid * PER + k;
+    if (i < n) doff[i] = off;
+    off += ln[k];
+  }
+  if (blockIdx.x == 0 && tid == 0) doff[n] = partial[n_tiles];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Byte copies.  General form: one thread per value (PLAIN, dictionary).  DELTA_LENGTH_BYTE_ARRAY pages are
+// one contiguous block each: flat 128-bit copy.
+// ---------------------------------------------------------------------------------------------
+// grid.x = data pages, grid.y = slices of the page; pages copied by the two special kernels are skipped
+__global__ __launch_bounds__(256) void k_copy_values(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, int flat_dlba,
+                                                     uint8_t *bytes_out) {
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  const int enc = c.pages[p].encoding;
+  if (enc == PQD_ENC_DELTA_BYTE_ARRAY || (flat_dlba && enc == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY)) return;
+  const PageState ps = c.state[p];
+  if (ps.status != 0) return;
+  for (int64_t k = (int64_t)blockIdx.y * 256 + threadIdx.x; k < ps.cnt; k += (int64_t)gridDim.y * 256) {
+    const int64_t i = ps.dense_base + k;
+    const uint64_t pr = pairs[i];
+    const uint8_t *src = c.in + (pr & kSrcMask);
+    uint8_t *dst = bytes_out + doff[i];
+    const int len = (int)(pr >> 40);
+    for (int b = 0; b < len; b++) dst[b] = src[b];
+  }
+}
+
+struct V16U { uint32_t v[4]; } __attribute__((packed));
+
+__global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out) {
+  // grid.x = data pages, grid.y = slices of the page
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
+  const PageState ps = c.state[p];
+  if (ps.status != 0 || ps.cnt <= 0) return;
+  const int64_t first = ps.dense_base;
+  const uint8_t *src = c.in + (pairs[first] & kSrcMask);
+  uint8_t *dst = bytes_out + doff[first];
+  const int64_t n = doff[first + ps.cnt] - doff[first];
+  for (int64_t b = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; b < n; b += (int64_t)gridDim.y * 256 * 16) {
+    if (b + 16 <= n) *reinterpret_cast<V16U *>(dst + b) = *reinterpret_cast<const V16U *>(src + b);
+    else for (int k = 0; b + k < n; k++) dst[b + k] = src[b + k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DELTA_BYTE_ARRAY: out[i] = out[i-1][:p_i] + suffix_i, the chain restarting at each page's first value
+// (whose own prefix length is ignored, encodingread.go:427).
+//
+// Byte k < p_i of string i is owned by the nearest earlier string j with p_j <= k (byte k - p_j of its
+// suffix).  parent[i] = nearest earlier string with a smaller prefix length; following parents from i-1
+// visits exactly the candidates in order of decreasing prefix length.  The parents are found by pointer
+// jumping: cand[i] starts at i-1 and jumps to cand[cand[i]] while p[cand[i]] >= p[i].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_dba_parents(ChunkCtx c, int64_t *prefix, int32_t *parent) {
+  __shared__ int s_changed;
+  __shared__ int s_bad;
+  const int d = blockIdx.x, tid = threadIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  const int cnt = ps->cnt;
+  if (tid == 0) { prefix[base] = 0; s_bad = 0; }
+  __syncthreads();
+  // parent index is page-relative; -1 = none (prefix 0 needs none)
+  for (int i = tid; i < cnt; i += 1024) {
+    const int64_t pi = prefix[base + i];
+    if (pi < 0 || pi > kMaxStrLen) s_bad = 1;
+    parent[base + i] = i - 1;
+  }
+  __syncthreads();
+  if (s_bad) { if (tid == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
+  for (int round = 0; round < 64; round++) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 1024) {
+      int j = parent[base + i];
+      if (j >= 0 && prefix[base + j] >= prefix[base + i]) {
+        parent[base + i] = parent[base + j];  // may read a value another lane updates this round: still a valid jump
+        s_changed = 1;
+      }
+    }
+    __syncthreads();
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // stragglers (adversarial inputs): finish serially per element
+  for (int i = tid; i < cnt; i += 1024) {
+    int j = parent[base + i];
+    const int64_t pi = prefix[base + i];
+    while (j >= 0 && prefix[base + j] >= pi) j = parent[base + j];
+    parent[base + i] = j;
+  }
+}
+
+// one thread per string: suffix bytes straight, prefix bytes through the parent chain
+__global__ __launch_bounds__(256) void k_dba_resolve(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int32_t *parent,
+                                                     const int64_t *doff, uint8_t *bytes_out) {
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  const int cnt = ps->cnt;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < cnt; i += gridDim.y * 256) {
+    const int64_t pi = prefix[base + i];
+    const uint64_t pr = pairs[base + i];
+    const int sl = (int)(pr >> 40);
+    uint8_t *dst = bytes_out + doff[base + i];
+    const uint8_t *suf = c.in + (pr & kSrcMask);
+    for (int b = 0; b < sl; b++) dst[pi + b] = suf[b];
+    if (pi > 0) {
+      // prefix longer than the previous string: the reference panics on the slice
+      const int64_t prev_len = prefix[base + i - 1] + (int64_t)(pairs[base + i - 1] >> 40);
+      if (pi > prev_len) { set_status_b(&ps->status, PQD_ERR_MALFORMED); continue; }
+      int j = i - 1;
+      int64_t pj = prefix[base + j];
+      const uint8_t *sj = c.in + (pairs[base + j] & kSrcMask);
+      for (int64_t k = pi - 1; k >= 0; k--) {
+        while (pj > k) {
+          j = parent[base + j];
+          pj = prefix[base + j];
+          sj = c.in + (pairs[base + j] & kSrcMask);
+        }
+        if (k - pj >= (int64_t)(pairs[base + j] >> 40)) { set_status_b(&ps->status, PQD_ERR_MALFORMED); break; }
+        dst[k] = sj[k - pj];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Null scatter of the offsets: slot s gets the offset of its value, null slots repeat the next offset
+// (zero length).  rank via the per-tile valid counts (exclusive-scanned) as in the fixed-width scatter.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_offsets(const int32_t *def, int64_t n_slots, int max_def, const int64_t *partial,
+                                                         const int64_t *doff, int64_t *slot_off) {
+  __shared__ int s_wave[4];
+  const int64_t base = (int64_t)blockIdx.x * 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t s0 = base + (int64_t)tid * 16;
+  uint32_t valid = 0;
+  for (int j = 0; j < 16; j++)
+    if (s0 + j < n_slots && def[s0 + j] == max_def) valid |= 1u << j;
+  int cnt = __builtin_popcount(valid);
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int q = 0; q < wv; q++) wbase += s_wave[q];
+  int64_t rank = partial[blockIdx.x] + wbase + incl - cnt;
+  for (int j = 0; j < 16; j++) {
+    const int64_t s = s0 + j;
+    if (s >= n_slots) break;
+    slot_off[s] = doff[rank];
+    rank += (valid >> j) & 1u;
+  }
+  if (s0 <= n_slots && n_slots < s0 + 16) slot_off[n_slots] = doff[rank];  // the grid covers index n_slots
+}
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_out, hipStream_t stream) {
+  if (which >= 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3(1), dim3(64), 0, stream, c, which, pairs_out);
+  else if (c.nd > 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3((c.nd + 63) / 64), dim3(64), 0, stream, c, which, pairs_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, encoding, lens, pairs_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
+                              hipStream_t stream) {
+  const int n_tiles = (int)((n + kScanTile - 1) / kScanTile);
+  if (n_tiles > 0) hipLaunchKernelGGL(k_len_tile_sums, dim3(n_tiles), dim3(256), 0, stream, pairs, prefix, n, partial);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, stream, partial, n_tiles);
+  hipLaunchKernelGGL(k_len_offsets, dim3(n_tiles > 0 ? n_tiles : 1), dim3(256), 0, stream, pairs, prefix, n, partial, n_tiles, doff);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
+                              hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_copy_values, dim3(c.nd, 16), dim3(256), 0, stream, c, pairs, doff, flat_dlba, bytes_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_copy_dlba_pages, dim3(c.nd, 32), dim3(256), 0, stream, c, pairs, doff, bytes_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
+                              uint8_t *bytes_out, int phase, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  if (phase == 0) hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent);
+  else hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, bytes_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_offsets(const int32_t *def, int64_t n_slots, int max_def, const int64_t *partial, const int64_t *doff,
+                                  int64_t *slot_off, hipStream_t stream) {
+  const int n_tiles = (int)((n_slots + 1 + 4095) / 4096);  // covers index n_slots itself
+  hipLaunchKernelGGL(k_scatter_offsets, dim3(n_tiles), dim3(256), 0, stream, def, n_slots, max_def, partial, doff, slot_off);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

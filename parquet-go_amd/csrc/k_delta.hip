@@ -133,8 +133,10 @@ __device__ __forceinline__ uint64_t gextract(const uint8_t *base16, uint32_t q, 
 
 // T = uint32_t (INT32 pages) or uint64_t (INT64 pages, and the length streams of the byte-array encodings).
 // MODE 0: values -> out[dense_base + i]
+// encoding: only pages with this value encoding are decoded.  src_sel 0: the stream starts at the page's value
+// section; 1: it starts where the previous delta stream of the page ended (PageState.aux0).
 template <class T>
-__global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out) {
+__global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, int encoding, int src_sel) {
   __shared__ uint4 ring4[2 * kSeg / 16];
   const uint32_t *ring = reinterpret_cast<const uint32_t *>(ring4);
   const int lane = threadIdx.x;
@@ -142,14 +144,15 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out) 
   const Stream *vs = &c.streams[2 * c.nd + d];
   const int p = vs->page;
   PageState *ps = &c.state[p];
-  if (c.pages[p].encoding != PQD_ENC_DELTA_BINARY_PACKED) return;
+  if (c.pages[p].encoding != encoding) return;
   const int64_t cnt = ps->cnt;
   if (ps->status != 0 || cnt <= 0) return;  // cnt == 0: ReadDataPageValues returns before reading
 
-  const uint8_t *abs0 = c.in + ps->val_off;
+  const int64_t src_off = src_sel ? ps->aux0 : ps->val_off;
+  const uint8_t *abs0 = c.in + src_off;
   const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(abs0) & 15u);
   const uint8_t *base16 = abs0 - a;
-  const uint32_t q_end = a + (uint32_t)ps->val_len;
+  const uint32_t q_end = a + (uint32_t)(ps->val_off + ps->val_len - src_off);
   T *out = values_out + ps->dense_base;
 
   int status = PQD_OK;
@@ -339,17 +342,17 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out) 
   }
   if (lane == 0) {
     if (status != PQD_OK) atomicCAS(&ps->status, 0, status);
-    ps->aux0 = ps->val_off + (int64_t)(q - a);  // where the delta stream ended (start of a byte-array payload)
+    ps->aux0 = src_off + (int64_t)(q - a);  // where the delta stream ended (start of a byte-array payload)
     ps->aux1 = (int64_t)n_values;
   }
 }
 
-hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, hipStream_t stream) {
+hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  if (c.elem_size == 4)
-    hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out));
+  if (elem_size == 4)
+    hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel);
   else
-    hipLaunchKernelGGL(k_delta_decode<uint64_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out));
+    hipLaunchKernelGGL(k_delta_decode<uint64_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out), encoding, src_sel);
   return hipGetLastError();
 }
 

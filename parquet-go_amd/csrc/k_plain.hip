@@ -239,6 +239,15 @@ hipError_t launch_plain_boolean(const ChunkCtx &c, const int32_t *tile_prefix, i
   return hipGetLastError();
 }
 
+// per-tile (4096 slots) counts of non-null slots, exclusive-scanned in place; n_tiles may exceed the slots
+hipError_t launch_scatter_rank(const int32_t *def_levels, int64_t n_slots, int max_def, int64_t *partial, int n_tiles,
+                               hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_count, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, max_def, partial);
+  hipLaunchKernelGGL(k_scatter_scan, dim3(1), dim3(1024), 0, stream, partial, n_tiles);
+  return hipGetLastError();
+}
+
 hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, const uint8_t *dense, uint8_t *out,
                                 int64_t n_slots, int64_t *scratch, hipStream_t stream) {
   if (n_slots <= 0) return hipSuccess;

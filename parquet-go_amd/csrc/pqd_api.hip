@@ -79,6 +79,8 @@ struct pqd_handle {
   bool profiling = false;
 
   DevBuf in, meta, runs, tile_run, dict, values, dense, def, rep, offsets, bytes, scratch, small;
+  DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
+  int64_t bytes_len = 0;
   PinnedBuf stage_in, stage_meta, host_small;
 
   // description of the last decode call
@@ -182,8 +184,14 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   h->nd = nd;
   h->total_slots = slots;
   const bool is_bytes = col->physical_type == PQD_BYTE_ARRAY;
-  if (is_bytes) { g_last_error = "BYTE_ARRAY columns are not implemented yet"; return PQD_ERR_UNSUPPORTED_TYPE; }
-  (void)any_other;
+  h->bytes_len = 0;
+  bool any_dlba = false, any_dba = false;
+  for (int p = 0; p < n_pages; p++) {
+    const PageIn &pi = h->h_pages[(size_t)p];
+    if (pi.data_idx < 0) continue;
+    if (pi.encoding == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) any_dlba = true;
+    if (pi.encoding == PQD_ENC_DELTA_BYTE_ARRAY) any_dba = true;
+  }
 
   // ---- meta block: pages | state | streams | tile prefixes | totals | status ----
   const size_t n_streams = (size_t)3 * nd;
@@ -258,16 +266,25 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
   if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
   const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
-  if ((rc = h->values.ensure(val_bytes))) return rc;
   const bool nullable = col->max_def > 0;
-  if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
+  if (!is_bytes) {
+    if ((rc = h->values.ensure(val_bytes))) return rc;
+    if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
+  } else {
+    const size_t n8 = 8 * ((size_t)slots + 2) + 64;
+    if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->offsets.ensure(n8))) return rc;
+    if ((any_dlba || any_dba) && (rc = h->lens64.ensure(n8))) return rc;
+    if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
+    if ((rc = h->scratch.ensure(8 * ((size_t)slots / 2048 + 8) + 64))) return rc;
+  }
   if (col->max_def > 0 && (rc = h->def.ensure(4 * (size_t)slots + 64))) return rc;
   if (col->max_rep > 0 && (rc = h->rep.ensure(4 * (size_t)slots + 64))) return rc;
   int dict_n = 0;
   if (dict_page >= 0) {
     dict_n = h->h_pages[(size_t)dict_page].num_values;
     if (dict_n < 0) dict_n = 0;
-    if ((rc = h->dict.ensure((size_t)dict_n * (size_t)esz + 64))) return rc;
+    if (!is_bytes && (rc = h->dict.ensure((size_t)dict_n * (size_t)esz + 64))) return rc;
+    if (is_bytes && (rc = h->dict_pairs.ensure(8 * (size_t)dict_n + 64))) return rc;
   }
 
   uint8_t *mb = static_cast<uint8_t *>(h->meta.p);
@@ -319,6 +336,71 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
+  if (is_bytes) {
+    // ---- BYTE_ARRAY: value descriptors (pairs) per encoding, offsets by a chunk-wide scan, then the copies ----
+    ChunkCtx c8 = c;
+    c8.elem_size = 8;
+    uint64_t *pairs = static_cast<uint64_t *>(h->pairs.p);
+    int64_t *lens64 = static_cast<int64_t *>(h->lens64.p);
+    int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
+    HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages leave zero lengths behind
+    if (dict_page >= 0) { Prof pf(h, "k_plain_ba_walk(dict)"); HIP_TRY(launch_plain_ba_walk(c, dict_page, static_cast<uint64_t *>(h->dict_pairs.p), h->stream)); }
+    if (any_dict_enc) {
+      if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
+      else {
+        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
+        { Prof pf(h, "k_hybrid_expand<dict>");
+          HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
+                                     reinterpret_cast<uint8_t *>(pairs), h->n_cu, h->stream)); }
+      }
+    }
+    if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, -1, pairs, h->stream)); }
+    if (any_dlba) {
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, h->stream)); }
+      { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
+    }
+    if (any_dba) {
+      HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
+      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, h->stream)); }
+      { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
+      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, nullptr, 0, h->stream)); }
+    }
+    for (int p = 0; p < n_pages && host_status == PQD_OK; p++) {
+      const PageIn &pi = h->h_pages[(size_t)p];
+      if (pi.data_idx < 0) continue;
+      const int e = pi.encoding;
+      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && e != PQD_ENC_DELTA_BYTE_ARRAY) {
+        host_status = PQD_ERR_UNSUPPORTED_ENCODING; host_bad = p;
+      }
+    }
+    // the number of non-null values sizes the scan; the byte total sizes the output: two small round trips
+    HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 64, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int64_t n_dense = static_cast<const int64_t *>(h->host_small.p)[1];
+    int64_t *doff = static_cast<int64_t *>(nullable ? h->doff.p : h->offsets.p);
+    { Prof pf(h, "k_len_offsets");
+      HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, n_dense, static_cast<int64_t *>(h->scratch.p), doff, h->stream)); }
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->host_small.p) + 128, doff + n_dense, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int64_t total_bytes = *reinterpret_cast<const int64_t *>(static_cast<const uint8_t *>(h->host_small.p) + 128);
+    if (total_bytes < 0 || total_bytes > ((int64_t)1 << 40)) { g_last_error = "implausible byte total"; return PQD_ERR_MALFORMED; }
+    h->bytes_len = total_bytes;
+    if ((rc = h->bytes.ensure((size_t)total_bytes + 64))) return rc;
+    uint8_t *bytes_out = static_cast<uint8_t *>(h->bytes.p);
+    bool all_dlba = any_dlba && !any_dba && !any_plain && !any_dict_enc;
+    if (any_plain || any_dict_enc || (any_dlba && !all_dlba)) { Prof pf(h, "k_copy_values"); HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, h->stream)); }
+    if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, bytes_out, h->stream)); }
+    if (any_dba) { Prof pf(h, "k_dba_resolve"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, bytes_out, 1, h->stream)); }
+    if (nullable) {
+      const int n_tiles = (int)((slots + 1 + 4095) / 4096);
+      if ((rc = h->scratch.ensure(8 * (size_t)n_tiles + 64))) return rc;
+      Prof pf(h, "k_scatter_offsets");
+      HIP_TRY(launch_scatter_rank(static_cast<const int32_t *>(h->def.p), slots, col->max_def, static_cast<int64_t *>(h->scratch.p), n_tiles, h->stream));
+      HIP_TRY(launch_scatter_offsets(static_cast<const int32_t *>(h->def.p), slots, col->max_def, static_cast<const int64_t *>(h->scratch.p), doff,
+                                     static_cast<int64_t *>(h->offsets.p), h->stream));
+    }
+  } else {
   if (dict_page >= 0) {
     if (h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN && h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN_DICTIONARY) {
       // the reference decodes every dictionary page as PLAIN whatever its header says (layout/page.go:802)
@@ -344,7 +426,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       host_status = host_status ? host_status : PQD_ERR_UNSUPPORTED_ENCODING;  // layout/page.go:682
     } else {
       Prof pf(h, "k_delta_decode");
-      HIP_TRY(launch_delta_decode(c, dense_out, h->stream));
+      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, h->stream));
     }
   }
   if (any_other && host_status == PQD_OK) {
@@ -363,6 +445,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     Prof pf(h, "k_scatter");
     HIP_TRY(launch_scatter_fixed(c, static_cast<const int32_t *>(h->def.p), static_cast<const uint8_t *>(h->dense.p),
                                  static_cast<uint8_t *>(h->values.p), slots, static_cast<int64_t *>(h->scratch.p), h->stream));
+  }
   }
   { Prof pf(h, "k_collect_status"); HIP_TRY(launch_collect_status(c, c.chunk_status, h->stream)); }
   HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
@@ -436,7 +519,8 @@ int pqd_handle_destroy(pqd_handle *h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
-                    &h->offsets, &h->bytes, &h->scratch, &h->small};
+                    &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
+                    &h->doff, &h->dict_pairs};
   for (DevBuf *b : bufs) b->release();
   h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -482,7 +566,7 @@ int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
     const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + 16;
     pqd_chunk_result &r = h->result;
     r.num_slots = tot[0]; r.num_values = tot[1]; r.num_nulls = tot[2]; r.num_rows = tot[3];
-    r.bytes_len = 0;
+    r.bytes_len = h->bytes_len;
     r.elem_size = h->elem_size;
     r.has_levels = (h->col.max_def > 0 ? 1 : 0) | (h->col.max_rep > 0 ? 2 : 0);
     if (r.status == PQD_OK) { r.status = st[0]; r.bad_page = st[1]; }
@@ -501,8 +585,10 @@ int pqd_result_device(pqd_handle *h, pqd_device_result *out) {
   out->values = h->values.p;
   out->def_levels = h->col.max_def > 0 ? static_cast<int32_t *>(h->def.p) : nullptr;
   out->rep_levels = h->col.max_rep > 0 ? static_cast<int32_t *>(h->rep.p) : nullptr;
-  out->offsets = nullptr;
-  out->bytes = nullptr;
+  const bool is_bytes = h->col.physical_type == PQD_BYTE_ARRAY;
+  if (is_bytes) out->values = nullptr;
+  out->offsets = is_bytes ? static_cast<int64_t *>(h->offsets.p) : nullptr;
+  out->bytes = is_bytes ? static_cast<uint8_t *>(h->bytes.p) : nullptr;
   return PQD_OK;
 }
 
@@ -511,7 +597,12 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
   if (!h->have_result) return fail_arg("no completed decode call");
   Guard g(h->device);
   const size_t n = (size_t)h->total_slots;
-  if (values && n) HIP_TRY(hipMemcpyAsync(values, h->values.p, n * (size_t)h->elem_size, hipMemcpyDeviceToHost, h->stream));
+  const bool is_bytes = h->col.physical_type == PQD_BYTE_ARRAY;
+  if (values && n && !is_bytes) HIP_TRY(hipMemcpyAsync(values, h->values.p, n * (size_t)h->elem_size, hipMemcpyDeviceToHost, h->stream));
+  if (is_bytes && h->result.status == PQD_OK) {
+    if (offsets) HIP_TRY(hipMemcpyAsync(offsets, h->offsets.p, 8 * (n + 1), hipMemcpyDeviceToHost, h->stream));
+    if (bytes && h->bytes_len) HIP_TRY(hipMemcpyAsync(bytes, h->bytes.p, (size_t)h->bytes_len, hipMemcpyDeviceToHost, h->stream));
+  }
   if (def_levels) {
     if (h->col.max_def > 0) { if (n) HIP_TRY(hipMemcpyAsync(def_levels, h->def.p, 4 * n, hipMemcpyDeviceToHost, h->stream)); }
     else std::memset(def_levels, 0, 4 * n);
@@ -520,7 +611,6 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
     if (h->col.max_rep > 0) { if (n) HIP_TRY(hipMemcpyAsync(rep_levels, h->rep.p, 4 * n, hipMemcpyDeviceToHost, h->stream)); }
     else std::memset(rep_levels, 0, 4 * n);
   }
-  (void)offsets; (void)bytes;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return PQD_OK;
 }

@@ -27,11 +27,29 @@ hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int
                               hipStream_t stream);
 hipError_t launch_plain_boolean(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
                                 hipStream_t stream);
+hipError_t launch_scatter_rank(const int32_t *def_levels, int64_t n_slots, int max_def, int64_t *partial, int n_tiles,
+                               hipStream_t stream);
 hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, const uint8_t *dense, uint8_t *out,
                                 int64_t n_slots, int64_t *scratch, hipStream_t stream);
 
 // ---- k_delta.hip ----
-// one wavefront per DELTA_BINARY_PACKED page; elem_size 4 or 8
-hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, hipStream_t stream);
+// one wavefront per page whose value encoding is `encoding`; elem_size 4 or 8; src_sel 1 continues at the end of
+// the page's previous delta stream
+hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel,
+                               hipStream_t stream);
+
+// ---- k_bytes.hip ----
+hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_out, hipStream_t stream);
+hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream);
+hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
+                              hipStream_t stream);
+hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
+                              hipStream_t stream);
+hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
+                                  hipStream_t stream);
+hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
+                              uint8_t *bytes_out, int phase, hipStream_t stream);
+hipError_t launch_scatter_offsets(const int32_t *def, int64_t n_slots, int max_def, const int64_t *partial, const int64_t *doff,
+                                  int64_t *slot_off, hipStream_t stream);
 
 }  // namespace pqd

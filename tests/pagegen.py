@@ -228,3 +228,29 @@ class ChunkBuilder:
 def dict_indices_body(idx, w, rng=None, style="mixed"):
     """Value section of a dictionary-encoded data page: width byte + hybrid runs (layout/page.go:644-655)."""
     return bytes([w]) + hybrid_encode(idx, w, rng, style)
+
+
+def plain_byte_array(strings):
+    """PLAIN BYTE_ARRAY: u32 length + bytes per value."""
+    return b"".join(struct.pack("<I", len(x)) + x for x in strings)
+
+
+def dlba_encode(strings, trim=False):
+    """DELTA_LENGTH_BYTE_ARRAY: DELTA_BINARY_PACKED lengths, then the bytes."""
+    if not strings:
+        return delta_encode(np.zeros(0, np.int32), np.int32)
+    return delta_encode(np.array([len(x) for x in strings], np.int32), np.int32, trim=trim) + b"".join(strings)
+
+
+def dba_encode(strings, trim=False):
+    """DELTA_BYTE_ARRAY: prefix lengths (shared with the previous value), then the suffixes as DELTA_LENGTH_BYTE_ARRAY."""
+    prefix, suffixes, prev = [], [], b""
+    for x in strings:
+        k = 0
+        m = min(len(prev), len(x))
+        while k < m and prev[k] == x[k]:
+            k += 1
+        prefix.append(k)
+        suffixes.append(x[k:])
+        prev = x
+    return delta_encode(np.array(prefix, np.int32), np.int32, trim=trim) + dlba_encode(suffixes, trim)

@@ -266,3 +266,126 @@ def test_device_resident_entry_point(dec, oracle):
     del t
     o = oracle.read_chunk(chunk, pages, oracle.INT32)
     assert g.status == 0 and np.array_equal(g.values, o.values)
+
+
+# ---------------------------------------------------------------------------------------------
+# BYTE_ARRAY
+# ---------------------------------------------------------------------------------------------
+def rand_strings(rng, n, lo=0, hi=40, alphabet=b"abcdefghijklmnopqrstuvwxyz0123456789"):
+    lens = rng.integers(lo, hi + 1, n)
+    pool = rng.integers(0, len(alphabet), int(lens.sum()) + 1)
+    ab = np.frombuffer(alphabet, np.uint8)
+    out, pos = [], 0
+    for ln in lens:
+        out.append(ab[pool[pos:pos + ln]].tobytes())
+        pos += ln
+    return out
+
+
+def sorted_keys(rng, n, lo=8, hi=64):
+    """Sorted keys sharing prefixes with their predecessor (prefix chains)."""
+    keys = sorted(set(rand_strings(rng, n, lo, hi, b"abc")))
+    return keys
+
+
+def test_byte_array_plain(dec, oracle):
+    rng = np.random.default_rng(60)
+    cb = pg.ChunkBuilder(gap=3, lead=1)
+    for n in (1, 2, 100, 5000):
+        cb.data_page_v1(pg.ENC_PLAIN, n, pg.plain_byte_array(rand_strings(rng, n)))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+
+
+def test_byte_array_dictionary(dec, oracle):
+    rng = np.random.default_rng(61)
+    words = rand_strings(rng, 700, 0, 30)
+    cb = pg.ChunkBuilder(gap=2)
+    cb.dict_page(pg.plain_byte_array(words), len(words))
+    for n, style in ((1, "rle"), (4097, "mixed"), (30000, "arrow")):
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, len(words), n), 10, rng, style))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    # the flat example's "name" column: one dictionary entry, width-32 RLE-only indices (example/local_flat.go)
+    cb = pg.ChunkBuilder()
+    cb.dict_page(pg.plain_byte_array([b"StudentName"]), 1)
+    cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, 100, bytes([32]) + oracle.write_rle_int32(np.zeros(100, np.int32), 32))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert g.bytes.tobytes() == b"StudentName" * 100
+
+
+@pytest.mark.parametrize("trim", [False, True])
+def test_delta_length_byte_array(dec, oracle, trim):
+    rng = np.random.default_rng(62)
+    cb = pg.ChunkBuilder(gap=1, lead=2)
+    cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, 4, oracle.write_delta_length_byte_array([b"Hello", b"World", b"Foobar", b"ABCDEF"]))
+    for n in (1, 2, 129, 3000, 20000):
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, n, pg.dlba_encode(rand_strings(rng, n, 0, 64), trim))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+
+
+@pytest.mark.parametrize("trim", [False, True])
+def test_delta_byte_array_prefix_chains(dec, oracle, trim):
+    rng = np.random.default_rng(63)
+    cb = pg.ChunkBuilder(gap=1)
+    cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, 4, oracle.write_delta_byte_array([b"Hello", b"World", b"Foobar", b"ABCDEF"]))
+    for n in (1, 2, 300, 5000, 30000):
+        keys = sorted_keys(rng, n)
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(keys), pg.dba_encode(keys, trim))
+    # adversarial chains: constant prefix lengths, strictly growing, strictly shrinking
+    same = [b"prefix-" + bytes([97 + i % 26]) for i in range(2000)]
+    grow = [b"x" * i for i in range(1, 300)]
+    shrink = [b"y" * i for i in range(300, 0, -1)]
+    for keys in (same, grow, shrink):
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(keys), pg.dba_encode(keys, trim))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+
+
+@pytest.mark.parametrize("enc", ["plain", "dict", "dlba", "dba"])
+def test_byte_array_with_nulls(dec, oracle, enc):
+    rng = np.random.default_rng(64)
+    cb = pg.ChunkBuilder()
+    words = rand_strings(rng, 50, 1, 12)
+    if enc == "dict":
+        cb.dict_page(pg.plain_byte_array(words), len(words))
+    for n in (10, 4096, 9001):
+        dl, rl = _levels(rng, n, 2, 1)
+        nn = int((dl == 2).sum())
+        if enc == "plain":
+            body, e = pg.plain_byte_array(rand_strings(rng, nn)), pg.ENC_PLAIN
+        elif enc == "dict":
+            body, e = pg.dict_indices_body(rng.integers(0, len(words), nn), 6, rng), pg.ENC_RLE_DICTIONARY
+        elif enc == "dlba":
+            body, e = pg.dlba_encode(rand_strings(rng, nn)), pg.ENC_DELTA_LENGTH_BYTE_ARRAY
+        else:
+            body, e = pg.dba_encode(sorted(rand_strings(rng, nn, 0, 20, b"ab"))), pg.ENC_DELTA_BYTE_ARRAY
+        if nn == 0:
+            body = b""
+        cb.data_page_v1(e, n, body, pg.level_block_v1(rl, 1, rng), pg.level_block_v1(dl, 2, rng))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY, 0, 2, 1)
+
+
+def test_byte_array_errors(dec, oracle):
+    # PLAIN value starting exactly at the end -> io.EOF
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(pg.ENC_PLAIN, 3, pg.plain_byte_array([b"ab", b"c"]))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == oracle.EOF
+    # DELTA_BYTE_ARRAY prefix longer than the previous string -> the reference panics
+    body = pg.delta_encode(np.array([0, 5], np.int32), np.int32) + pg.dlba_encode([b"abc", b"d"])
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, 2, body)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == oracle.PANIC
+    # fewer strings than the page holds
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, 5, pg.dlba_encode([b"a", b"b"]))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == oracle.PANIC
