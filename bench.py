@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the DELTA_BINARY_PACKED / host-to-host extras")
     ap.add_argument("--delta-values", type=int, default=512 << 20)
+    ap.add_argument("--iso-reps", type=int, default=3, help="serial launches per width for the isolated kernel durations")
     return ap.parse_args()
 
 
@@ -154,30 +155,50 @@ def main():
     out_bytes_step = len(widths) * n_values * 4
     value = world * out_bytes_step * args.steps / elapsed / 1e9
 
-    # ---- roofline of the dominant kernel (expand + gather), from HIP events around each launch ----
-    per_width = {}
-    exp_ms = exp_bytes = 0.0
-    exp_n = 0
+    # ---- the same chunks once more, one at a time on one stream: per-kernel durations without other chunks' kernels
+    # sharing the CUs (the durations taken inside the timed region above include that sharing) ----
+    iso = {}
+    for item in work:
+        for _ in range(args.iso_reps):
+            submit(item, dec)
+            dec.wait()
+            for name, (ms, n) in dec.kernel_times().items():
+                e = iso.setdefault((item["w"], name), [0.0, 0])
+                e[0] += ms
+                e[1] += n
+
+    # ---- roofline of the dominant kernel (bit unpack + dictionary gather), from HIP events around each launch ----
+    def expand_stats(kt):
+        per_width, tot_ms, tot_bytes, tot_n = {}, 0.0, 0.0, 0
+        for item in work:
+            w = item["w"]
+            ms, n = kt.get((w, "k_hybrid_expand<dict>"), (0.0, 0))
+            pre_ms, _ = kt.get((w, "k_hybrid_prescan(dict)"), (0.0, 0))
+            alg = item["in_bytes"] + n_values * 4 + item["dict_n"] * 4  # packed input + decoded output + dictionary
+            if n:
+                per_width[str(w)] = {"expand_ms": round(ms / n, 4), "prescan_ms": round(pre_ms / n, 4),
+                                     "expand_GBps": round(alg / (ms / n) / 1e6, 1),
+                                     "alg_bytes_per_value": round(alg / n_values, 4)}
+                tot_ms += ms
+                tot_bytes += alg * n
+                tot_n += n
+        gbps = tot_bytes / tot_ms / 1e6 if tot_ms else 0.0
+        return per_width, gbps, (tot_ms / tot_n if tot_n else None)
+
     all_ms = {}
     for (w, name), (ms, n) in ktimes.items():
         all_ms[name] = all_ms.get(name, 0.0) + ms
-    for item in work:
-        w = item["w"]
-        ms, n = ktimes.get((w, "k_hybrid_expand<dict>"), (0.0, 0))
-        pre_ms, _ = ktimes.get((w, "k_hybrid_prescan(dict)"), (0.0, 0))
-        alg = item["in_bytes"] + n_values * 4 + item["dict_n"] * 4  # packed input + decoded output + dictionary
-        if n:
-            per_width[str(w)] = {"expand_ms": round(ms / n, 4), "prescan_ms": round(pre_ms / n, 4),
-                                 "expand_GBps": round(alg / (ms / n) / 1e6, 1),
-                                 "alg_bytes_per_value": round(alg / n_values, 4)}
-            exp_ms += ms
-            exp_bytes += alg * n
-            exp_n += n
-    achieved = exp_bytes / exp_ms / 1e6 if exp_ms else 0.0
+    per_width, achieved, avg_ms = expand_stats(ktimes)
+    iso_pw, iso_gbps, iso_avg = expand_stats(iso)
     roofline = {"bound": "hbm", "kernel": "k_hybrid_expand<dict> (bit unpack + dictionary gather)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "avg_launch_ms": round(exp_ms / exp_n, 4) if exp_n else None, "per_width": per_width,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args, widths),
+                "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "per_width": per_width,
+                "note": "durations from HIP events on each handle's stream inside the timed region, where %d chunks are "
+                        "in flight and their kernels share the CUs; 'isolated' is the same launch with the GPU to itself"
+                        % n_handles,
+                "isolated": {"achieved": round(iso_gbps, 1), "frac": round(iso_gbps / HBM_PEAK_GBPS, 4),
+                             "avg_launch_ms": round(iso_avg, 4) if iso_avg else None, "per_width": iso_pw},
                 "kernel_ms_share": {k: round(v / max(sum(all_ms.values()), 1e-9), 4) for k, v in all_ms.items()}}
 
     extra = {}
@@ -204,6 +225,21 @@ def main():
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def measured_traffic(args, widths):
+    """HBM bytes per launch of the expand kernel from the memory-side L2 counters.  The counters need rocprofv3, which
+    cannot run inside this process, so the figure comes from the committed summary of profiles/pmc_expand.sh for this
+    very workload shape; None when no summary matches."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("values_per_gpu") != args.values or t.get("page_values") != args.page_values or t.get("widths") != widths:
+        return None
+    return t.get("traffic")
 
 
 def run_extras(args, dec, local_rank):
