@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import parquet_go_amd as pq  # noqa: E402
+from parquet_go_amd import sharding  # noqa: E402
 from gen import pqgen  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
@@ -133,24 +134,16 @@ def main():
     for item in work:
         item["host"] = None
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    # warm-up, then exactly --steps timed steps between barrier + device sync on both sides, MAX over ranks
+    collect_flag = [False]
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(collect=True)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def one_step():
+        step(collect=collect_flag[0])
+
+    dist = torch.distributed if world > 1 else None
+    sharding.timed_region(one_step, 0, args.warmup, sync=torch.cuda.synchronize, dist=dist, device="cuda")
+    collect_flag[0] = True
+    elapsed = sharding.timed_region(one_step, args.steps, 0, sync=torch.cuda.synchronize, dist=dist, device="cuda")
 
     out_bytes_step = len(widths) * n_values * 4
     value = world * out_bytes_step * args.steps / elapsed / 1e9

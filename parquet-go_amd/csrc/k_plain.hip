@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_plain_fixed(PlainArgs a) {
     const Stream *vs = &c.streams[2 * c.nd + lo];
     const int p = vs->page;
     PageState *ps = &c.state[p];
-    if (ps->status != 0) continue;
+    if (ps->status != 0 || c.pages[p].encoding != PQD_ENC_PLAIN) continue;
     const int64_t cnt = ps->cnt;
     const int64_t bytes = cnt * (int64_t)c.elem_size;
     if (k == 0 && threadIdx.x == 0) {
@@ -88,6 +88,64 @@ __global__ __launch_bounds__(256) void k_plain_fixed(PlainArgs a) {
     if (first >= bytes) continue;
     block_copy_tile(c.in + ps->val_off, ps->val_len, a.values_out + ps->dense_base * (int64_t)c.elem_size, bytes, first,
                     kPlainTile);
+  }
+}
+
+// ---- data pages, BYTE_STREAM_SPLIT FLOAT / DOUBLE: byte k of value i sits at cnt*k + i ----
+// encoding/encodingread.go:437-485: one io.ReadFull of cnt*size bytes, then the byte-plane transpose.
+// A thread assembles four consecutive values from one 4-byte read per plane.
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_byte_stream_split(PlainArgs a) {
+  const ChunkCtx &c = a.c;
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    int lo = 0, hi = c.nd;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (a.tile_prefix[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const int k = tile - a.tile_prefix[lo];
+    const Stream *vs = &c.streams[2 * c.nd + lo];
+    const int p = vs->page;
+    PageState *ps = &c.state[p];
+    if (ps->status != 0 || c.pages[p].encoding != PQD_ENC_BYTE_STREAM_SPLIT) continue;
+    const int64_t cnt = ps->cnt;
+    const int st = plain_fixed_status(c.physical_type, ps->val_len, cnt, ESZ);
+    if (st) {
+      if (k == 0 && threadIdx.x == 0) set_status1(&ps->status, st);
+      continue;
+    }
+    const uint8_t *src = c.in + ps->val_off;
+    uint8_t *dst = a.values_out + ps->dense_base * (int64_t)ESZ;
+    constexpr int kTileValues = kPlainTile / ESZ;
+    const int64_t v0 = (int64_t)k * kTileValues;
+    for (int o = threadIdx.x * 4; o < kTileValues; o += 256 * 4) {
+      const int64_t i = v0 + o;
+      if (i >= cnt) break;
+      if (i + 4 <= cnt) {
+        uint32_t plane[ESZ];
+#pragma unroll
+        for (int b = 0; b < ESZ; b++) plane[b] = reinterpret_cast<const V16Unaligned *>(src + cnt * b + i)->v[0];
+        uint32_t out[ESZ];  // four values of ESZ bytes = ESZ dwords
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int d = 0; d < ESZ / 4; d++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) x |= ((plane[4 * d + b] >> (8 * j)) & 0xFFu) << (8 * b);
+            out[j * (ESZ / 4) + d] = x;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < ESZ / 4; q++) {
+          V16Unaligned x = {{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]}};
+          *reinterpret_cast<V16Unaligned *>(dst + i * ESZ + 16 * q) = x;
+        }
+      } else {
+        for (int64_t j = i; j < cnt; j++)
+          for (int b = 0; b < ESZ; b++) dst[j * ESZ + b] = src[cnt * b + j];
+      }
+    }
   }
 }
 
@@ -227,6 +285,16 @@ hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int
   PlainArgs a{c, tile_prefix, n_tiles, values_out};
   int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
   hipLaunchKernelGGL(k_plain_fixed, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_byte_stream_split(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+                                    hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  PlainArgs a{c, tile_prefix, n_tiles, values_out};
+  int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
+  if (c.elem_size == 4) hipLaunchKernelGGL(k_byte_stream_split<4>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_byte_stream_split<8>, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

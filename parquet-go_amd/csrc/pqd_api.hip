@@ -157,7 +157,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   int nd = 0, dict_page = -1, n_dict = 0;
   int64_t slots = 0;
   int host_status = PQD_OK, host_bad = -1;
-  bool any_dict_enc = false, any_plain = false, any_delta = false, any_other = false;
+  bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_other = false;
+  const bool is_real = col->physical_type == PQD_FLOAT || col->physical_type == PQD_DOUBLE;
   for (int p = 0; p < n_pages; p++) {
     const pqd_page_desc &d = pages[p];
     PageIn &pi = h->h_pages[(size_t)p];
@@ -172,6 +173,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       if (is_dict_enc(d.encoding)) any_dict_enc = true;
       else if (d.encoding == PQD_ENC_PLAIN) any_plain = true;
       else if (d.encoding == PQD_ENC_DELTA_BINARY_PACKED) any_delta = true;
+      else if (d.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real) any_bss = true;  // layout/page.go:707-714
       else any_other = true;
     } else if (d.page_type == PQD_DICTIONARY_PAGE) {
       if (n_dict == 0) dict_page = p;
@@ -219,7 +221,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
         else {
           tp_dict[(size_t)d] = (int32_t)t_dc; t_dc += tiles;
           tp_plain[(size_t)d] = (int32_t)t_pl;
-          if (pi.encoding == PQD_ENC_PLAIN) {
+          if (pi.encoding == PQD_ENC_PLAIN || (pi.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
             const int64_t units = col->physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)esz;
             t_pl += (units + kPlainTile - 1) / kPlainTile;
           }
@@ -421,6 +423,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
   }
+  if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
   if (any_delta) {
     if (col->physical_type != PQD_INT32 && col->physical_type != PQD_INT64) {
       host_status = host_status ? host_status : PQD_ERR_UNSUPPORTED_ENCODING;  // layout/page.go:682
@@ -434,7 +437,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       const PageIn &pi = h->h_pages[(size_t)p];
       if (pi.data_idx < 0) continue;
       const int e = pi.encoding;
-      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_BINARY_PACKED) {
+      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_BINARY_PACKED && !(e == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
         host_status = PQD_ERR_UNSUPPORTED_ENCODING; host_bad = p; break;
       }
     }

@@ -25,6 +25,8 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
 hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream);
 hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
                               hipStream_t stream);
+hipError_t launch_byte_stream_split(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+                                    hipStream_t stream);
 hipError_t launch_plain_boolean(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
                                 hipStream_t stream);
 hipError_t launch_scatter_rank(const int32_t *def_levels, int64_t n_slots, int max_def, int64_t *partial, int n_tiles,

@@ -193,6 +193,34 @@ def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
     check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
 
 
+@pytest.mark.parametrize("ptype,dt", [(pg.FLOAT, np.float32), (pg.DOUBLE, np.float64)])
+def test_byte_stream_split(dec, oracle, ptype, dt):
+    rng = np.random.default_rng(61 + ptype)
+    cb = pg.ChunkBuilder(gap=3, lead=1)
+    esz = np.dtype(dt).itemsize
+    for n, nullable in ((1, False), (3, False), (4, False), (5, False), (4097, True), (70001, False), (16384, True)):
+        dl = (rng.random(n) < 0.8).astype(np.int64) if nullable else np.ones(n, np.int64)
+        nn = int(dl.sum())
+        vals = rng.standard_normal(nn).astype(dt)
+        body = vals.view(np.uint8).reshape(nn, esz).T.tobytes()   # plane k = byte k of every value
+        cb.data_page_v1(9, n, body, b"", pg.level_block_v1(dl, 1, rng))
+    # mixed with a PLAIN page, and a short section
+    cb.data_page_v1(pg.ENC_PLAIN, 7, rng.standard_normal(7).astype(dt).tobytes(), b"", pg.level_block_v1(np.ones(7, np.int64), 1))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype, 0, 1, 0)
+    assert o.status == 0
+    cb.data_page_v1(9, 10, b"\0" * (10 * esz - 1), b"", pg.level_block_v1(np.ones(10, np.int64), 1))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype, 0, 1, 0)
+    assert o.status == oracle.UNEXPECTED_EOF
+    # not defined for integer columns (layout/page.go:713)
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(9, 4, b"\0" * 16)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
+    assert o.status == oracle.UNSUPPORTED
+
+
 def test_empty_and_all_null(dec, oracle):
     cb = pg.ChunkBuilder()
     chunk, pages = cb.finish()

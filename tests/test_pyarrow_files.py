@@ -29,6 +29,8 @@ def make_table(n, rng, nulls):
         "i64_delta": mask((1_700_000_000_000_000 + np.cumsum(rng.integers(1000, 5000, n))).astype(np.int64)),
         "i32_delta": mask(np.cumsum(rng.integers(-50, 50, n)).astype(np.int32)),
         "f32_plain": mask(rng.random(n).astype(np.float32)),
+        "f32_bss": mask(rng.standard_normal(n).astype(np.float32)),
+        "f64_bss": mask(rng.standard_normal(n).astype(np.float64)),
         "f64_dict": mask(rng.integers(0, 50, n).astype(np.float64) / 7.0),
         "bool_plain": mask(rng.integers(0, 2, n).astype(bool)),
         "str_plain": mask(np.array(["s%d" % x for x in rng.integers(0, 10**6, n)], dtype=object)),
@@ -55,6 +57,7 @@ def write_file(path, table, version):
         table, path, compression="NONE", data_page_version=version, data_page_size=8 * 1024, write_statistics=False,
         use_dictionary=["i32_dict", "f64_dict", "str_dict", "list_i64"],
         column_encoding={"i64_delta": "DELTA_BINARY_PACKED", "i32_delta": "DELTA_BINARY_PACKED", "f32_plain": "PLAIN",
+                         "f32_bss": "BYTE_STREAM_SPLIT", "f64_bss": "BYTE_STREAM_SPLIT",
                          "bool_plain": "PLAIN", "str_plain": "PLAIN", "str_dlba": "DELTA_LENGTH_BYTE_ARRAY",
                          "str_dba": "DELTA_BYTE_ARRAY", "flba": "PLAIN"},
         row_group_size=len(table) // 2 + 1)
@@ -134,7 +137,7 @@ def test_oracle_matches_pyarrow(parquet_file, oracle):
         check_table(t, f, rg, name, ptype, max_def, num_values)
         # rows: one per slot with repetition level 0
         assert t.n_rows == f.metadata.row_group(rg).num_rows
-    assert {0, 5, 6, 7}.issubset(seen_enc) and (2 in seen_enc or 8 in seen_enc)
+    assert {0, 5, 6, 7, 9}.issubset(seen_enc) and (2 in seen_enc or 8 in seen_enc)
 
 
 @pytest.mark.gpu
