@@ -1,0 +1,539 @@
+// Tile expansion of RLE / bit-packed hybrid streams on gfx950: run table -> values.
+// Levels become int32 arrays (+ null and row counts); dictionary indices are gathered straight into the
+// value array.
+//
+// Reference behaviour reproduced here: encoding/encodingread.go:146-167 (RLE run), :170-228 (bit-packed run),
+// layout/page.go:139-164 (dictionary gather), :835-888 (levels, null count), :925-927 (row count).
+#include <hip/hip_runtime.h>
+#include "pqd_kernels.h"
+
+namespace pqd {
+
+__device__ __forceinline__ void set_status(int32_t *p, int code) { atomicCAS(p, 0, code); }  // first error wins
+
+struct U32x4Unaligned { uint32_t v[4]; } __attribute__((packed));
+struct U64x2Unaligned { uint64_t v[2]; } __attribute__((packed));
+struct U64Unaligned { uint64_t v; } __attribute__((packed));
+
+constexpr int kSegBytes = 128;  // run index of the first item of every 64-item segment of a tile (32 entries)
+
+struct ExpandArgs {
+  ChunkCtx c;
+  const int32_t *tile_prefix;  // n_streams + 1 entries
+  const int32_t *tile_stream;  // n_tiles entries: stream (relative to stream0) of each tile
+  int stream0;
+  int n_tiles;
+  int32_t *rep_out, *def_out;  // levels
+  const uint8_t *dict;         // dictionary, elem_size bytes per entry, 16-byte aligned and padded
+  int32_t dict_n;
+  int32_t dict_lds_n;          // entries [0, dict_lds_n) are staged in LDS
+  int32_t dict_lds_bytes;      // LDS reserved for them (multiple of 16)
+  int32_t runs_cap;            // run-slice entries a group keeps in LDS (+ 3)
+  int32_t mark_cap;            // items per tile the mark array holds
+  int32_t stage_bytes;         // LDS bytes for the packed bytes of one tile (multiple of 16)
+  int32_t group_bytes;         // LDS of one group: runs | segments | marks | packed bytes
+  uint8_t *values_out;
+  TileDesc *descs;             // n_tiles entries, written by k_tile_desc
+};
+
+__host__ __device__ inline int runs_lds_bytes(int runs_cap) { return (runs_cap + 3) * (int)sizeof(RunEntry); }
+__host__ __device__ inline int marks_lds_bytes(int mark_cap) { return (mark_cap * 2 + 15) / 16 * 16; }
+
+// w bits at bit position `bit` (relative to `payload`) of the stream; bytes at or beyond `avail` are zero.
+__device__ __forceinline__ uint32_t extract_bits(const uint8_t *sbase, uint32_t avail, uint32_t payload, uint64_t bit,
+                                                 int w) {
+  uint64_t byte = (uint64_t)payload + (bit >> 3);
+  uint32_t sh = (uint32_t)bit & 7u;
+  uint64_t x;
+  if (byte + 8 <= (uint64_t)avail) {
+    x = reinterpret_cast<const U64Unaligned *>(sbase + byte)->v;
+  } else {
+    x = 0;
+    for (int k = 0; k < 8; k++)
+      if (byte + k < (uint64_t)avail) x |= (uint64_t)sbase[byte + k] << (8 * k);
+  }
+  uint32_t mask = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+  return (uint32_t)(x >> sh) & mask;
+}
+
+// Values v .. v+n4-1 of a stream straight from global memory (any number of runs): binary search for the run
+// holding v, then a walk.
+__device__ __forceinline__ void decode4(const RunEntry *R, int nr, int v, int n4, const uint8_t *sbase, uint32_t avail,
+                                        int w, uint32_t out[4]) {
+  int lo = 0, hi = nr - 1;  // largest i in [0, nr-2] with start(i) <= v
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if ((int)(R[mid].x & 0x7FFFFFFFu) <= v) lo = mid; else hi = mid;
+  }
+  int i = lo;
+  uint32_t ex = R[i].x, ey = R[i].y;
+  int start = (int)(ex & 0x7FFFFFFFu);
+  int next = (int)(R[i + 1].x & 0x7FFFFFFFu);
+  for (int j = 0; j < n4; j++) {
+    const int vv = v + j;
+    while (vv >= next) {
+      i++;
+      ex = R[i].x; ey = R[i].y;
+      start = (int)(ex & 0x7FFFFFFFu);
+      next = (int)(R[i + 1].x & 0x7FFFFFFFu);
+    }
+    if ((ex >> 31) == 0) out[j] = ey;
+    else out[j] = extract_bits(sbase, avail, ey, (uint64_t)(uint32_t)(vv - start) * (uint32_t)w, w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tile_desc: one thread per tile, after the prescan: which runs, items and stream bytes the tile covers.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
+  const int tile = blockIdx.x * 256 + threadIdx.x;
+  if (tile >= a.n_tiles) return;
+  const ChunkCtx &c = a.c;
+  TileDesc d;
+  d.flags = 0;
+  const int ls = a.tile_stream[tile];
+  const int k = tile - a.tile_prefix[ls];
+  const Stream *sp = &c.streams[a.stream0 + ls];
+  const int cnt = sp->cnt;
+  d.t0 = k * kTile;
+  d.page = sp->page;
+  d.pad = 0;
+  if (sp->status != 0 || d.t0 >= cnt) {
+    d.in_off = 0; d.out_elem = 0; d.run0 = 0; d.item_lo = 0; d.n_items = 0; d.t1 = d.t0; d.org = 0; d.span = 0; d.nr = 0;
+    d.avail = 0; d.w = 0;
+    a.descs[tile] = d;
+    return;
+  }
+  d.t1 = cnt < d.t0 + kTile ? cnt : d.t0 + kTile;
+  const int2 *tile_run = reinterpret_cast<const int2 *>(c.tile_run) + sp->tile_base;
+  const int2 tk = tile_run[k];
+  const bool last_tile = !(d.t0 + kTile < cnt);
+  const int2 tk1 = last_tile ? make_int2(sp->n_runs - 1, sp->pad) : tile_run[k + 1];
+  const int r0 = tk.x, r1 = tk1.x;
+  d.nr = r1 - r0 + 2;
+  d.run0 = sp->run_base + r0;
+  const RunEntry *gruns = c.runs + d.run0;
+  d.in_off = sp->off;
+  d.avail = sp->avail;
+  d.w = sp->w;
+  d.out_elem = sp->out_base;
+  const uint32_t w = (uint32_t)d.w;
+  // items of the tile: from the item holding value t0 to the one holding value t1 - 1
+  const RunEntry e0 = gruns[0];
+  const int start0 = (int)(e0.x & 0x7FFFFFFFu);
+  const uint32_t k0 = (uint32_t)(d.t0 - start0) >> 3;
+  d.item_lo = e0.z + k0;
+  RunEntry eL = gruns[d.nr - 2];
+  if ((int)(eL.x & 0x7FFFFFFFu) >= d.t1) eL = gruns[d.nr - 3];  // the next tile starts with a run of its own
+  const uint32_t item_hi = eL.z + ((uint32_t)(d.t1 - 1 - (int)(eL.x & 0x7FFFFFFFu)) >> 3) + 1u;
+  d.n_items = (int)(item_hi - d.item_lo);
+  // stream bytes the tile can touch: from its first group (or the header of its first run) to the position of
+  // the next tile's first value plus one group; org is 16-byte aligned in memory
+  const int b_lo = (e0.x >> 31) ? (int)(e0.y + k0 * w) : tk.y;
+  const int b_hi = tk1.y + (int)w + 1;
+  d.org = b_lo - (int)((reinterpret_cast<uintptr_t>(c.in + d.in_off) + (uintptr_t)(uint32_t)b_lo) & 15u);
+  d.span = b_hi - d.org;
+  const bool in_lds = d.nr <= a.runs_cap + 2 && d.span + 8 <= a.stage_bytes && d.n_items <= a.mark_cap;
+  d.flags = 1 | (in_lds ? 2 : 0) | ((a.stream0 + ls) >= c.nd ? 4 : 0);
+  a.descs[tile] = d;
+}
+
+// One bit-packed group: W bytes at byte offset `rel` of the staging buffer -> eight values.
+// The bytes are fetched as aligned dwords, realigned by the byte offset, then every value sits at a
+// compile-time bit position.
+template <int W>
+__device__ __forceinline__ void unpack8(const uint32_t *s_stage, uint32_t rel, uint32_t x[8]) {
+  if (W == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = 0;
+    return;
+  }
+  constexpr int ND = W == 0 ? 1 : (W + 3) / 4;
+  constexpr uint32_t mask = W >= 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
+  const uint32_t a = rel >> 2, sb = (rel & 3u) * 8u;
+  uint32_t raw[ND + 1];
+#pragma unroll
+  for (int i = 0; i <= ND; i++) raw[i] = s_stage[a + i];
+  uint32_t d[ND + 1];
+#pragma unroll
+  for (int i = 0; i < ND; i++) d[i] = __builtin_amdgcn_alignbit(raw[i + 1], raw[i], sb);
+  d[ND] = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int bit = j * W, lo = bit >> 5, sh = bit & 31;
+    if (sh + W <= 32) x[j] = (d[lo] >> sh) & mask;
+    else x[j] = __builtin_amdgcn_alignbit(d[lo + 1], d[lo], (uint32_t)sh) & mask;
+  }
+}
+
+// inclusive running maximum over the 64 lanes (DPP row shifts, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
+  uint32_t y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;  // row_bcast:15
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;  // row_bcast:31
+  return x;
+}
+
+// Stores values j0 .. j1-1 of an item (eight output elements starting at `outp`).
+__device__ __forceinline__ void store_item(uint32_t *outp, const uint32_t y[8], int j0, int j1) {
+  if (j0 == 0 && j1 == 8) {
+    U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}}, o1 = {{y[4], y[5], y[6], y[7]}};
+    reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0;
+    reinterpret_cast<U32x4Unaligned *>(outp)[1] = o1;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (j >= j0 && j < j1) outp[j] = y[j];
+  }
+}
+__device__ __forceinline__ void store_item(uint64_t *outp, const uint64_t y[8], int j0, int j1) {
+  if (j0 == 0 && j1 == 8) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      U64x2Unaligned o = {{y[2 * q], y[2 * q + 1]}};
+      reinterpret_cast<U64x2Unaligned *>(outp)[q] = o;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (j >= j0 && j < j1) outp[j] = y[j];
+  }
+}
+
+// DMODE 0: dictionary in global memory; 1: whole dictionary in LDS; 2: entries below dict_lds_n in LDS, the
+// rest in global memory.  (Separate code paths: a run-time choice of address space would turn every lookup
+// into a flat load.)
+template <int DMODE, class T>
+__device__ __forceinline__ T dict_lookup(const ExpandArgs &a, const uint8_t *s_dict, uint32_t idx) {
+  if (DMODE == 0) return reinterpret_cast<const T *>(a.dict)[idx];
+  if (DMODE == 1) return reinterpret_cast<const T *>(s_dict)[idx];
+  if (idx < (uint32_t)a.dict_lds_n) return reinterpret_cast<const T *>(s_dict)[idx];
+  return reinterpret_cast<const T *>(a.dict)[idx];
+}
+
+// The items of one staged tile.  GT threads; a wave takes 64 consecutive items per step.  The run holding an
+// item: the running maximum, over the items before it, of the marks the runs left at their first item.
+template <int MODE, int DMODE, int GT, int W>
+__device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc &d, const RunEntry *s_runs,
+                                             const int *s_seg, uint16_t *s_mark, const uint32_t *s_stage,
+                                             const uint8_t *s_dict, int gtid, uint32_t staged, int &n_flag,
+                                             bool &bad_index) {
+  const ChunkCtx &c = a.c;
+  const int lane = gtid & 63;
+  const int tn = d.t1 - d.t0;
+  const bool is_def = (d.flags & 4) != 0;
+  const bool check_bp = MODE != 0 && !(W < 32 && (1u << (W & 31)) <= (uint32_t)a.dict_n);  // can a packed index be out of range
+  for (int q0 = gtid - lane; q0 < d.n_items; q0 += GT) {
+    const int q = q0 + lane;
+    const bool active = q < d.n_items;
+    uint32_t r = (uint32_t)s_seg[q0 >> 6];
+    if (active) {
+      const uint32_t m = s_mark[q];
+      s_mark[q] = 0;  // left clean for the next tile
+      r = r > m ? r : m;
+    }
+    r = wave_incl_max(r);
+    if (!active) continue;
+    const RunEntry e = s_runs[r];
+    const int next_rel = (int)(s_runs[r + 1].x & 0x7FFFFFFFu) - d.t0;
+    const uint32_t kk = d.item_lo + (uint32_t)q - e.z;
+    const int vrel = (int)(e.x & 0x7FFFFFFFu) - d.t0 + (int)(kk << 3);  // tile-relative position of the item's value 0
+    const int j0 = vrel < 0 ? -vrel : 0;
+    const int lim = next_rel < tn ? next_rel : tn;
+    const int j1 = lim - vrel < 8 ? lim - vrel : 8;
+    uint32_t x[8];
+    const bool bp = e.x >> 31;
+    if (bp) {
+      const uint32_t rel = e.y - (uint32_t)d.org + kk * (uint32_t)W;
+      if (rel + (uint32_t)W + 8u <= staged) {
+        unpack8<W>(s_stage, rel, x);
+      } else {
+        // a payload cut short by the end of the stream: bytes that are not there read as zero
+        for (int j = 0; j < 8; j++)
+          x[j] = extract_bits(c.in + d.in_off, (uint32_t)d.avail, e.y, (uint64_t)(kk * 8u + (uint32_t)j) * (uint32_t)W, W);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = e.y;
+    }
+    const int64_t oidx = d.out_elem + d.t0 + vrel;
+
+    if (MODE == 0) {
+      int32_t *outp = (is_def ? a.def_out : a.rep_out) + oidx;
+      const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+#pragma unroll
+      for (int j = 0; j < 8; j++) n_flag += (j >= j0 && j < j1) && (is_def ? (x[j] != cmp) : (x[j] == cmp));
+      store_item(reinterpret_cast<uint32_t *>(outp), x, j0, j1);
+    } else if (MODE == 4 || MODE == 8) {
+      if (bp ? check_bp : true) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (x[j] >= (uint32_t)a.dict_n) { bad_index = bad_index || (j >= j0 && j < j1); x[j] = 0; }
+      }
+      if (MODE == 4) {
+        uint32_t y[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
+        store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
+      } else {
+        uint64_t y[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint64_t>(a, s_dict, x[j]);
+        store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
+      }
+    } else {
+      const int esz = c.elem_size;
+      for (int j = j0; j < j1; j++) {
+        uint32_t idx = x[j];
+        if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
+        uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
+        const bool in_lds = DMODE == 1 || (DMODE == 2 && idx < (uint32_t)a.dict_lds_n);
+        if (in_lds) { const uint8_t *src = s_dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
+        else { const uint8_t *src = a.dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
+      }
+    }
+  }
+}
+
+// MODE 0: levels -> int32 (+ counts); MODE 4 / 8: dictionary gather of 4- / 8-byte elements;
+// MODE 1: dictionary gather of elem_size-byte elements (BOOLEAN, INT96, FIXED_LEN_BYTE_ARRAY)
+// G groups of GT threads per block; a group expands one tile at a time.
+//
+// Per tile (kTile consecutive values of one stream): the run slice and the packed bytes the tile needs are
+// staged in LDS with coalesced 128-bit loads (every input byte is read from HBM once).  The tile's work is then
+// cut into items - up to eight consecutive values of one run, a whole bit-packed group where the run is bit
+// packed - and each lane takes one item at a time: either a fill (RLE) or the unpack of one byte-aligned group
+// with compile-time bit positions, then the dictionary lookups and two 16-byte stores.
+template <int MODE, int DMODE, int G, int GT>
+__global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const TileDesc *__restrict__ descs) {
+  extern __shared__ uint4 smem[];
+  uint8_t *lds = reinterpret_cast<uint8_t *>(smem);
+  const int g = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
+  const int gtid = G == 1 ? (int)threadIdx.x : (int)threadIdx.x % GT;
+  uint8_t *area = lds + a.dict_lds_bytes + g * a.group_bytes;
+  RunEntry *s_runs = reinterpret_cast<RunEntry *>(area);
+  int *s_seg = reinterpret_cast<int *>(area + runs_lds_bytes(a.runs_cap));
+  uint16_t *s_mark = reinterpret_cast<uint16_t *>(area + runs_lds_bytes(a.runs_cap) + kSegBytes);
+  uint32_t *s_stage = reinterpret_cast<uint32_t *>(area + runs_lds_bytes(a.runs_cap) + kSegBytes + marks_lds_bytes(a.mark_cap));
+  const uint8_t *s_dict = lds;
+  const ChunkCtx &c = a.c;
+  const int esz = c.elem_size;
+
+  if (DMODE != 0) {
+    const int nvec = (a.dict_lds_n * esz + 15) / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.dict);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < nvec; i += G * GT) dst[i] = src[i];
+  }
+  for (int i = gtid; i < marks_lds_bytes(a.mark_cap) / 16; i += GT) reinterpret_cast<uint4 *>(s_mark)[i] = make_uint4(0, 0, 0, 0);
+
+  const int stride = (int)gridDim.x * G;
+  int tile = (int)blockIdx.x * G + g;
+  TileDesc d_next = {};
+  if (tile < a.n_tiles) d_next = descs[tile];
+  for (int base = (int)blockIdx.x * G; base < a.n_tiles; base += stride, tile += stride) {
+    const TileDesc d = d_next;
+    d_next.flags = 0;
+    if (tile + stride < a.n_tiles) d_next = descs[tile + stride];  // in flight while this tile is expanded
+    const bool valid = (d.flags & 1) != 0;
+    const bool in_lds = (d.flags & 2) != 0;
+    const RunEntry *gruns = c.runs + d.run0;
+    const uint8_t *sbase = c.in + d.in_off;
+    const int nvec = (d.span + 8 + 15) >> 4;
+    const uint32_t staged = (uint32_t)nvec * 16u;
+
+    __syncthreads();  // the previous tile is done with LDS (first pass: dictionary and marks are in place after the next one)
+    if (in_lds) {
+      // run slice, segment table, marks and packed bytes: all loads issued before the one barrier
+      const uint32_t item_lo = d.item_lo, item_hi = d.item_lo + (uint32_t)d.n_items;
+      for (int i = gtid; i < d.nr; i += GT) {
+        const RunEntry e = gruns[i];
+        s_runs[i] = e;
+        if (i < d.nr - 1) {
+          // the 64-item segments whose first item run i holds
+          const uint32_t zn = gruns[i + 1].z;
+          const int ia = e.z <= item_lo ? 0 : (int)(e.z - item_lo);
+          const int ib = zn >= item_hi ? d.n_items : (zn <= item_lo ? 0 : (int)(zn - item_lo));
+          for (int j = (ia + 63) >> 6; (j << 6) < ib; j++) s_seg[j] = i;
+          // a mark at the run's first item (the previous tile's readers cleared theirs before the barrier above)
+          if (i >= 1 && e.z > item_lo && e.z < item_hi) s_mark[e.z - item_lo] = (uint16_t)i;
+        }
+      }
+      if (gtid == 0) s_runs[d.nr] = RunEntry{0x7FFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+      for (int i = gtid; i < nvec; i += GT) {
+        const int sp0 = d.org + 16 * i;  // stream position of this vector
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (sp0 < d.avail) {
+          x = *reinterpret_cast<const uint4 *>(sbase + sp0);
+          const int left = d.avail - sp0;
+          if (left < 16) {
+            uint32_t wv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int lb = left - 4 * q;
+              if (lb <= 0) wv[q] = 0;
+              else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
+            }
+            x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+          }
+        }
+        reinterpret_cast<uint4 *>(s_stage)[i] = x;
+      }
+    }
+    __syncthreads();
+
+    int n_flag = 0;  // levels: nulls or rows counted by this thread
+    bool bad_index = false;
+    if (in_lds) {
+      switch (__builtin_amdgcn_readfirstlane(d.w)) {
+#define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
+        PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
+        PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
+        PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
+        PQD_CASE(25) PQD_CASE(26) PQD_CASE(27) PQD_CASE(28) PQD_CASE(29) PQD_CASE(30) PQD_CASE(31) PQD_CASE(32)
+#undef PQD_CASE
+        default: break;
+      }
+    } else if (valid) {
+      // tiles with more runs or bytes than the LDS budget: four values per lane straight from global memory
+      for (int it = 0; it < kTile / (GT * 4); it++) {
+        const int rel = it * GT * 4 + gtid * 4;
+        const int v = d.t0 + rel;
+        if (v >= d.t1) continue;
+        const int n4 = d.t1 - v < 4 ? d.t1 - v : 4;
+        uint32_t x[4] = {0, 0, 0, 0};
+        decode4(gruns, d.nr, v, n4, sbase, (uint32_t)d.avail, d.w, x);
+        if (MODE == 0) {
+          const bool is_def = (d.flags & 4) != 0;
+          int32_t *outp = (is_def ? a.def_out : a.rep_out) + d.out_elem + v;
+          const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+          for (int j = 0; j < n4; j++) {
+            n_flag += is_def ? (x[j] != cmp) : (x[j] == cmp);
+            outp[j] = (int32_t)x[j];
+          }
+        } else {
+          for (int j = 0; j < n4; j++) {
+            uint32_t idx = x[j];
+            if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
+            uint8_t *dst = a.values_out + (size_t)(d.out_elem + v + j) * esz;
+            const uint8_t *src = a.dict + (size_t)idx * esz;
+            if (MODE == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+            else if (MODE == 8) *reinterpret_cast<uint64_t *>(dst) = *reinterpret_cast<const uint64_t *>(src);
+            else for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb];
+          }
+        }
+      }
+    }
+
+    if (MODE == 0) {
+      // wave reduction, one atomic per wave
+      for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
+      if ((gtid & 63) == 0 && n_flag) atomicAdd((d.flags & 4) ? &c.state[d.page].n_nulls : &c.state[d.page].n_rows, n_flag);
+    } else {
+      if (bad_index) set_status(&c.state[d.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
+    }
+  }
+}
+
+constexpr int kLdsTotal = 160 * 1024;
+constexpr int kStageMax = 18 * 1024;  // packed bytes of one tile, at most
+
+static int clamp_stage(int stage_bytes) {
+  int sb = (stage_bytes + 15) / 16 * 16;
+  if (sb < 1024) sb = 1024;
+  if (sb > kStageMax) sb = kStageMax;
+  return sb;
+}
+
+static void set_group_layout(ExpandArgs &a, int runs_cap, int stage_bytes) {
+  a.runs_cap = runs_cap;
+  a.mark_cap = kTile / 8 + runs_cap + 8;
+  a.stage_bytes = clamp_stage(stage_bytes);
+  a.group_bytes = runs_lds_bytes(a.runs_cap) + kSegBytes + marks_lds_bytes(a.mark_cap) + a.stage_bytes;
+}
+
+template <class K>
+static hipError_t launch_expand(K kern, const ExpandArgs &a, int grid, int threads, size_t shmem, hipStream_t stream) {
+  if (shmem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_tile_desc, dim3((a.n_tiles + 255) / 256), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), shmem, stream, a, a.descs);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+                                int stage_bytes, int32_t *rep_out, int32_t *def_out, TileDesc *descs, int n_cu,
+                                hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  ExpandArgs a;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 0; a.n_tiles = n_tiles;
+  a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.dict_lds_n = 0; a.dict_lds_bytes = 0;
+  a.values_out = nullptr; a.descs = descs;
+  set_group_layout(a, kRunSlice, stage_bytes);
+  int per_cu = kLdsTotal / (a.group_bytes + 512);
+  if (per_cu > 8) per_cu = 8;
+  int grid = n_cu * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  return launch_expand(&k_hybrid_expand<0, 0, 1, 256>, a, grid, 256, (size_t)a.group_bytes, stream);
+}
+
+hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+                              int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
+                              int n_cu, hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  ExpandArgs a;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
+  a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out; a.descs = descs;
+  const int esz = c.elem_size;
+  const size_t dict_bytes = ((size_t)dict_n * esz + 15) / 16 * 16;
+  const bool fixed48 = esz == 4 || esz == 8;
+
+  if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024) {
+    // small dictionaries: whole dictionary in the LDS of every block, several 256-thread blocks per CU.
+    // Large ones of other element sizes, and very large ones: gathered from L2 / HBM.
+    const bool lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;
+    a.dict_lds_n = lds ? dict_n : 0;
+    a.dict_lds_bytes = lds ? (int)dict_bytes : 0;
+    set_group_layout(a, kRunSlice, stage_bytes);
+    const size_t shmem = (size_t)a.dict_lds_bytes + a.group_bytes;
+    int per_cu = (int)(kLdsTotal / (shmem + 512));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int grid = n_cu * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    if (esz == 4) return lds ? launch_expand(&k_hybrid_expand<4, 1, 1, 256>, a, grid, 256, shmem, stream)
+                             : launch_expand(&k_hybrid_expand<4, 0, 1, 256>, a, grid, 256, shmem, stream);
+    if (esz == 8) return lds ? launch_expand(&k_hybrid_expand<8, 1, 1, 256>, a, grid, 256, shmem, stream)
+                             : launch_expand(&k_hybrid_expand<8, 0, 1, 256>, a, grid, 256, shmem, stream);
+    return lds ? launch_expand(&k_hybrid_expand<1, 1, 1, 256>, a, grid, 256, shmem, stream)
+               : launch_expand(&k_hybrid_expand<1, 0, 1, 256>, a, grid, 256, shmem, stream);
+  }
+
+  // Mid-size dictionaries (48 KiB .. 1 MiB of 4- or 8-byte entries): one 1024-thread block per CU, two groups of
+  // 512 threads, and all the LDS the tiles do not need holds the head of the dictionary; indices beyond it
+  // are gathered from L2.  A random 4-byte gather is bound by the L2 request rate, so every entry that sits
+  // in LDS counts.
+  constexpr int G = 2, GT = 512;
+  set_group_layout(a, 254, stage_bytes);
+  int room = kLdsTotal - G * a.group_bytes - 256;
+  room = room / 16 * 16;
+  if (room < 0) room = 0;
+  a.dict_lds_bytes = (size_t)room < dict_bytes ? room : (int)dict_bytes;
+  a.dict_lds_n = (size_t)room >= dict_bytes ? dict_n : a.dict_lds_bytes / esz;
+  const size_t shmem = (size_t)a.dict_lds_bytes + (size_t)G * a.group_bytes;
+  int grid = n_cu;
+  if (grid > (n_tiles + G - 1) / G) grid = (n_tiles + G - 1) / G;
+  const bool whole = a.dict_lds_n >= dict_n;
+  if (esz == 4) return whole ? launch_expand(&k_hybrid_expand<4, 1, G, GT>, a, grid, G * GT, shmem, stream)
+                             : launch_expand(&k_hybrid_expand<4, 2, G, GT>, a, grid, G * GT, shmem, stream);
+  return whole ? launch_expand(&k_hybrid_expand<8, 1, G, GT>, a, grid, G * GT, shmem, stream)
+               : launch_expand(&k_hybrid_expand<8, 2, G, GT>, a, grid, G * GT, shmem, stream);
+}
+
+}  // namespace pqd

@@ -1,5 +1,5 @@
-// RLE / bit-packed hybrid streams on gfx950: page setup, run-header prescan, tile expansion
-// (levels and dictionary gather) and the per-page bookkeeping between them.
+// RLE / bit-packed hybrid streams on gfx950: page setup, run-header prescan and the per-page bookkeeping
+// around the tile expansion (k_expand.hip).
 //
 // Reference behaviour reproduced here:
 //   encoding/encodingread.go:127-143 (varint), :146-167 (RLE run), :170-228 (bit-packed run),
@@ -115,9 +115,6 @@ __global__ void k_page_setup(ChunkCtx c) {
 // 128-bit accesses, the next window prefetched into registers while the current one is walked;
 // every lane executes the same walk on wave-uniform scalars.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRunLdsBytes = ((int)sizeof(RunEntry) * (kRunSlice + 3) + 15) / 16 * 16;   // run slice + end marker
-constexpr int kSegLdsBytes = 128;                                                    // segment table
-constexpr int kStageMax = 18 * 1024;                                                 // packed bytes of one tile, at most
 constexpr int kWin = 4096;           // window bytes
 constexpr int kWinVec = kWin / 16 + 4;  // 16-byte vectors per window incl. 64 bytes look-ahead
 constexpr int kWinPerLane = (kWinVec + 63) / 64;
@@ -199,7 +196,8 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   uint32_t emit_end = 0;
   uint32_t emit_q = a;             // stream position (q-space) after the last emitted run
   int nr = 0;
-  uint32_t ex = 0, ey = 0;         // this lane's pending run entry
+  uint32_t ex = 0, ey = 0, ez = 0; // this lane's pending run entry
+  uint32_t items = 0;              // work items of the runs emitted so far
   int status = PQD_OK;
 
   // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
@@ -252,9 +250,10 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
         if (__builtin_expect(kt < endc, 0))
           for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
             tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
-        if (lane == (nr & 63)) { ex = e_x; ey = e_y; }
+        if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; }
         nr++;
-        if (__builtin_expect((nr & 63) == 0, 0)) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
+        items += (nv + 7u) >> 3;
+        if (__builtin_expect((nr & 63) == 0, 0)) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
         emit_end = endv;
         emit_q = q;
         o32 = endv;
@@ -349,9 +348,10 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
         if (kt < endc)
           for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
             tile_run[k] = make_int2(nr, (int)((e_x >> 31) ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - start) * (uint32_t)w) >> 3) : run_q - a));
-        if (lane == (nr & 63)) { ex = e_x | start; ey = e_y; }
+        if (lane == (nr & 63)) { ex = e_x | start; ey = e_y; ez = items; }
         nr++;
-        if ((nr & 63) == 0) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
+        items += (nv + 7u) >> 3;
+        if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
         emit_end = e64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)e64;
         emit_q = q;
       }
@@ -360,12 +360,12 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   }
   // end sentinel, then flush the partial group
   const int n_runs = nr;
-  if (lane == (nr & 63)) { ex = emit_end; ey = 0; }
+  if (lane == (nr & 63)) { ex = emit_end; ey = 0; ez = items; }
   nr++;
-  if ((nr & 63) == 0) { runs[nr - 64 + lane].x = ex; runs[nr - 64 + lane].y = ey; }
+  if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
   {
     int pending = nr & 63;
-    if (lane < pending) { runs[nr - pending + lane].x = ex; runs[nr - pending + lane].y = ey; }
+    if (lane < pending) runs[nr - pending + lane] = RunEntry{ex, ey, ez, 0u};
   }
   if (status == PQD_OK && out < (uint64_t)cnt) status = PQD_ERR_MALFORMED;  // buf[:cnt] past the decoded values
   if (lane == 0) {
@@ -373,339 +373,6 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
     sp->pad = (int32_t)(emit_q - a);  // end of the bytes the emitted runs occupy
     sp->decoded = (int64_t)out;
     if (status != PQD_OK) sp->status = status;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tile expansion.  A tile is kTile consecutive values of one stream; 256 threads decode 4 consecutive
-// values each per iteration, so a wavefront's stores cover 1 KiB of contiguous output.
-// ---------------------------------------------------------------------------------------------
-struct U32x4Unaligned { uint32_t v[4]; } __attribute__((packed));
-struct U64x2Unaligned { uint64_t v[2]; } __attribute__((packed));
-struct U64Unaligned { uint64_t v; } __attribute__((packed));
-
-// w bits at bit position `bit` (relative to `payload`) of the stream; bytes at or beyond `avail` are zero.
-__device__ __forceinline__ uint32_t extract_bits(const uint8_t *sbase, uint32_t avail, uint32_t payload, uint64_t bit,
-                                                 int w) {
-  uint64_t byte = (uint64_t)payload + (bit >> 3);
-  uint32_t sh = (uint32_t)bit & 7u;
-  uint64_t x;
-  if (byte + 8 <= (uint64_t)avail) {
-    x = reinterpret_cast<const U64Unaligned *>(sbase + byte)->v;
-  } else {
-    x = 0;
-    for (int k = 0; k < 8; k++)
-      if (byte + k < (uint64_t)avail) x |= (uint64_t)sbase[byte + k] << (8 * k);
-  }
-  uint32_t mask = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
-  return (uint32_t)(x >> sh) & mask;
-}
-
-template <class RunPtr>
-__device__ __forceinline__ void decode4(RunPtr R, int nr, int v, int n4, const uint8_t *sbase, uint32_t avail, int w,
-                                        uint32_t out[4]) {
-  // largest i in [0, nr-2] with start(i) <= v
-  int lo = 0, hi = nr - 1;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if ((int)(R[mid].x & 0x7FFFFFFFu) <= v) lo = mid; else hi = mid;
-  }
-  int i = lo;
-  uint32_t ex = R[i].x, ey = R[i].y;
-  int start = (int)(ex & 0x7FFFFFFFu);
-  int next = (int)(R[i + 1].x & 0x7FFFFFFFu);
-  if (v + n4 <= next) {
-    if ((ex >> 31) == 0) {
-      out[0] = out[1] = out[2] = out[3] = ey;
-      return;
-    }
-    uint64_t bit = (uint64_t)(uint32_t)(v - start) * (uint32_t)w;
-    uint64_t byte = (uint64_t)ey + (bit >> 3);
-    uint32_t sh = (uint32_t)bit & 7u;
-    if (w <= 30 && byte + 16 <= (uint64_t)avail) {
-      U64x2Unaligned x = *reinterpret_cast<const U64x2Unaligned *>(sbase + byte);
-      uint32_t mask = (1u << w) - 1u;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        uint32_t b = sh + (uint32_t)(j * w);  // < 128
-        uint64_t lo64 = x.v[0], hi64 = x.v[1];
-        uint64_t y;
-        if (b >= 64) y = hi64 >> (b - 64);
-        else y = (lo64 >> b) | (b ? (hi64 << (64 - b)) : 0);
-        out[j] = (uint32_t)y & mask;
-      }
-      return;
-    }
-    for (int j = 0; j < n4; j++) out[j] = extract_bits(sbase, avail, ey, bit + (uint64_t)(j * w), w);
-    return;
-  }
-  // the four values straddle runs
-  for (int j = 0; j < n4; j++) {
-    int vv = v + j;
-    while (vv >= next) {
-      i++;
-      ex = R[i].x; ey = R[i].y;
-      start = (int)(ex & 0x7FFFFFFFu);
-      next = (int)(R[i + 1].x & 0x7FFFFFFFu);
-    }
-    if ((ex >> 31) == 0) out[j] = ey;
-    else out[j] = extract_bits(sbase, avail, ey, (uint64_t)(uint32_t)(vv - start) * (uint32_t)w, w);
-  }
-}
-
-struct ExpandArgs {
-  ChunkCtx c;
-  const int32_t *tile_prefix;  // n_streams + 1 entries
-  const int32_t *tile_stream;  // n_tiles entries: stream (relative to stream0) of each tile
-  int n_streams;
-  int stream0;
-  int n_tiles;
-  int32_t *rep_out, *def_out;  // levels
-  const uint8_t *dict;         // dictionary, elem_size bytes per entry, 16-byte aligned and padded
-  int32_t dict_n;
-  int32_t dict_lds;            // stage the dictionary in LDS
-  int32_t stage_bytes;         // LDS bytes for the packed bytes of one tile (multiple of 16)
-  uint8_t *values_out;
-};
-
-// Values v .. v+n4-1 of a stream given the run index i of the run holding v (general path: straight from
-// global memory, any number of runs).
-template <class RunPtr>
-__device__ __forceinline__ void decode4_at(RunPtr R, int i, int v, int n4, const uint8_t *sbase, uint32_t avail, int w,
-                                           uint32_t out[4]) {
-  uint32_t ex = R[i].x, ey = R[i].y;
-  int start = (int)(ex & 0x7FFFFFFFu);
-  int next = (int)(R[i + 1].x & 0x7FFFFFFFu);
-  for (int j = 0; j < n4; j++) {
-    const int vv = v + j;
-    while (vv >= next) {
-      i++;
-      ex = R[i].x; ey = R[i].y;
-      start = (int)(ex & 0x7FFFFFFFu);
-      next = (int)(R[i + 1].x & 0x7FFFFFFFu);
-    }
-    if ((ex >> 31) == 0) out[j] = ey;
-    else out[j] = extract_bits(sbase, avail, ey, (uint64_t)(uint32_t)(vv - start) * (uint32_t)w, w);
-  }
-}
-
-struct TileCtx {
-  int t0, t1, nr, w, page;
-  uint32_t avail;
-  const uint8_t *sbase;
-  int64_t out_base;
-  bool in_lds, is_def;
-  int org;  // stream position of the first staged byte (may be slightly negative)
-};
-
-// MODE 0: levels -> int32 (+ counts); MODE 4 / 8: dictionary gather of 4- / 8-byte elements;
-// MODE 1: dictionary gather of elem_size-byte elements (BOOLEAN, INT96, FIXED_LEN_BYTE_ARRAY)
-//
-// Per tile: the run slice and the packed bytes the tile needs are staged in LDS with coalesced 128-bit loads
-// (every input byte is read from HBM once); each lane then decodes four consecutive values: a branch-free
-// binary search over the runs of its wave's 256-value segment, two-dword LDS reads per value, funnel shift,
-// mask, dictionary lookup, one 16-byte store.  A wave's stores cover 1 KiB of contiguous output.
-template <int MODE, bool DICT_LDS>
-__global__ __launch_bounds__(256) void k_hybrid_expand(ExpandArgs a) {
-  extern __shared__ uint4 smem[];
-  RunEntry *s_runs = reinterpret_cast<RunEntry *>(smem);
-  int *s_seg = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes);  // kTile / 256 + 1 entries
-  uint32_t *s_stage = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes);
-  const uint8_t *s_dict = reinterpret_cast<const uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
-  const int tid = threadIdx.x;
-  const ChunkCtx &c = a.c;
-  const int esz = c.elem_size;
-
-  if (MODE != 0 && DICT_LDS) {
-    const int nvec = (a.dict_n * esz + 15) / 16;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.dict);
-    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(smem) + kRunLdsBytes + kSegLdsBytes + a.stage_bytes);
-    for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
-  }
-
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int ls = a.tile_stream[tile];
-    const int k = tile - a.tile_prefix[ls];
-    const Stream *sp = &c.streams[a.stream0 + ls];
-    const int cnt = sp->cnt;
-    TileCtx t;
-    t.t0 = k * kTile;
-    if (sp->status != 0 || t.t0 >= cnt) continue;
-    t.t1 = cnt < t.t0 + kTile ? cnt : t.t0 + kTile;
-    const int2 *tile_run = reinterpret_cast<const int2 *>(c.tile_run) + sp->tile_base;
-    const int2 tk = tile_run[k];
-    const bool last_tile = !(t.t0 + kTile < cnt);
-    const int2 tk1 = last_tile ? make_int2(sp->n_runs - 1, sp->pad) : tile_run[k + 1];
-    const int r0 = tk.x, r1 = tk1.x;
-    t.nr = r1 - r0 + 2;
-    const RunEntry *gruns = c.runs + sp->run_base + r0;
-    t.sbase = c.in + sp->off;
-    t.avail = (uint32_t)sp->avail;
-    t.w = sp->w;
-    t.out_base = sp->out_base;
-    t.page = sp->page;
-    t.is_def = (a.stream0 + ls) >= c.nd;
-    const uint32_t w = (uint32_t)t.w;
-    const uint32_t mask = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
-    // stream bytes the tile can touch: from the position of its first value to the position of the next tile's
-    // first value (or the end of the last run) plus the reach of one value; org is 16-byte aligned in memory
-    const int b_lo = tk.y;
-    const int b_hi = tk1.y + (int)((w + 7) >> 3) + 1;
-    t.org = b_lo - (int)((reinterpret_cast<uintptr_t>(t.sbase) + (uintptr_t)(uint32_t)b_lo) & 15u);
-    const int span = b_hi - t.org;
-    t.in_lds = t.nr <= kRunSlice + 2 && span + 8 <= a.stage_bytes;
-
-    __syncthreads();  // the previous tile is done with LDS
-    if (t.in_lds) {
-      // run slice, segment table and packed bytes: all loads issued before the one barrier
-      for (int i = tid; i < t.nr; i += 256) {
-        const RunEntry e = gruns[i];
-        s_runs[i] = e;
-        if (i < t.nr - 1) {
-          // the 256-value segments whose first value run i holds
-          const int st = (int)(e.x & 0x7FFFFFFFu), nx = (int)(gruns[i + 1].x & 0x7FFFFFFFu);
-          int j = st <= t.t0 ? 0 : (st - t.t0 + 255) >> 8;
-          for (; j <= kTile / 256 && t.t0 + j * 256 < nx; j++) s_seg[j] = i;
-        } else {
-          // i is the end marker: segments at or beyond the end of the last run
-          const int last_end = (int)(e.x & 0x7FFFFFFFu);
-          int j = last_end <= t.t0 ? 0 : (last_end - t.t0 + 255) >> 8;
-          for (; j <= kTile / 256; j++) s_seg[j] = t.nr - 2;
-        }
-      }
-      if (tid == 0) { s_runs[t.nr].x = 0x7FFFFFFFu; s_runs[t.nr].y = 0; }
-      const int nvec = (span + 8 + 15) >> 4;
-      for (int i = tid; i < nvec; i += 256) {
-        const int sp0 = t.org + 16 * i;  // stream position of this vector
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (sp0 < (int)t.avail) {
-          x = *reinterpret_cast<const uint4 *>(t.sbase + sp0);
-          const int left = (int)t.avail - sp0;
-          if (left < 16) {
-            uint32_t wv[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int lb = left - 4 * q;
-              if (lb <= 0) wv[q] = 0;
-              else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
-            }
-            x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-          }
-        }
-        reinterpret_cast<uint4 *>(s_stage)[i] = x;
-      }
-      __syncthreads();
-    }
-
-    int n_flag = 0;  // levels: nulls or rows counted by this thread
-    bool bad_index = false;
-#pragma unroll
-    for (int it = 0; it < kTile / 1024; it++) {
-      const int rel = it * 1024 + tid * 4;
-      const int v = t.t0 + rel;
-      if (v >= t.t1) continue;
-      const int n4 = t.t1 - v < 4 ? t.t1 - v : 4;
-      uint32_t x[4] = {0, 0, 0, 0};
-      if (t.in_lds) {
-        // branch-free search of the run holding v among the runs of this wave's segment (uniform bounds)
-        const int seg = rel >> 8;
-        const int s_lo = __builtin_amdgcn_readfirstlane(s_seg[seg]);
-        const int s_hi = __builtin_amdgcn_readfirstlane(s_seg[seg + 1]);
-        int lo = s_lo, up = s_hi + 1;
-        for (int span = s_hi - s_lo; span > 0; span >>= 1) {
-          const int mid = (lo + up) >> 1;
-          const bool le = (int)(s_runs[mid].x & 0x7FFFFFFFu) <= v;
-          lo = le ? mid : lo;
-          up = le ? up : mid;
-        }
-        const int i = lo;
-        const uint32_t exA = s_runs[i].x, eyA = s_runs[i].y, exB = s_runs[i + 1].x, eyB = s_runs[i + 1].y;
-        const int startA = (int)(exA & 0x7FFFFFFFu), nextA = (int)(exB & 0x7FFFFFFFu);
-        const int nextB = (int)(s_runs[i + 2].x & 0x7FFFFFFFu);
-        if (v + n4 > nextB) {
-          // three or more runs within four values
-          decode4_at(s_runs, i, v, n4, t.sbase, t.avail, t.w, x);
-        } else {
-          const bool bpA = exA >> 31, bpB = exB >> 31;
-          // bit position in the staging buffer of value v of run A / run B (mod 2^32; the true value is small)
-          const uint32_t baseA = ((eyA - (uint32_t)t.org) << 3) + (uint32_t)(v - startA) * w;
-          const uint32_t baseB = ((eyB - (uint32_t)t.org) << 3) + (uint32_t)(v - nextA) * w;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const bool inA = v + j < nextA;
-            const bool bp = inA ? bpA : bpB;
-            const uint32_t P = bp ? (inA ? baseA : baseB) + (uint32_t)j * w : 0u;
-            const uint32_t d0 = s_stage[P >> 5], d1 = s_stage[(P >> 5) + 1];
-            const uint32_t bits = __builtin_amdgcn_alignbit(d1, d0, P & 31u) & mask;
-            x[j] = bp ? bits : (inA ? eyA : eyB);
-          }
-        }
-      } else {
-        decode4(gruns, t.nr, v, n4, t.sbase, t.avail, t.w, x);
-      }
-
-      if (MODE == 0) {
-        int32_t *outp = (t.is_def ? a.def_out : a.rep_out) + t.out_base + v;
-        const uint32_t cmp = t.is_def ? (uint32_t)c.max_def : 0u;
-        for (int j = 0; j < n4; j++) n_flag += t.is_def ? (x[j] != cmp) : (x[j] == cmp);
-        if (n4 == 4) {
-          U32x4Unaligned o = {{x[0], x[1], x[2], x[3]}};
-          *reinterpret_cast<U32x4Unaligned *>(outp) = o;
-        } else {
-          for (int j = 0; j < n4; j++) outp[j] = (int32_t)x[j];
-        }
-      } else if (MODE == 4) {
-        uint32_t y[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          uint32_t idx = x[j];
-          if (idx >= (uint32_t)a.dict_n) { bad_index = bad_index || (j < n4); idx = 0; }
-          // (kept as two code paths: a run-time choice of address space would turn every lookup into a flat load)
-          if (DICT_LDS) y[j] = reinterpret_cast<const uint32_t *>(s_dict)[idx];
-          else y[j] = reinterpret_cast<const uint32_t *>(a.dict)[idx];
-        }
-        uint32_t *outp = reinterpret_cast<uint32_t *>(a.values_out) + t.out_base + v;
-        if (n4 == 4) {
-          U32x4Unaligned o = {{y[0], y[1], y[2], y[3]}};
-          *reinterpret_cast<U32x4Unaligned *>(outp) = o;
-        } else {
-          for (int j = 0; j < n4; j++) outp[j] = y[j];
-        }
-      } else if (MODE == 8) {
-        uint64_t y[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          uint32_t idx = x[j];
-          if (idx >= (uint32_t)a.dict_n) { bad_index = bad_index || (j < n4); idx = 0; }
-          if (DICT_LDS) y[j] = reinterpret_cast<const uint64_t *>(s_dict)[idx];
-          else y[j] = reinterpret_cast<const uint64_t *>(a.dict)[idx];
-        }
-        uint64_t *outp = reinterpret_cast<uint64_t *>(a.values_out) + t.out_base + v;
-        if (n4 == 4) {
-          U64x2Unaligned o0 = {{y[0], y[1]}}, o1 = {{y[2], y[3]}};
-          reinterpret_cast<U64x2Unaligned *>(outp)[0] = o0;
-          reinterpret_cast<U64x2Unaligned *>(outp)[1] = o1;
-        } else {
-          for (int j = 0; j < n4; j++) outp[j] = y[j];
-        }
-      } else {
-        for (int j = 0; j < n4; j++) {
-          uint32_t idx = x[j];
-          if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-          uint8_t *dst = a.values_out + (size_t)(t.out_base + v + j) * esz;
-          if (DICT_LDS) { const uint8_t *src = s_dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
-          else { const uint8_t *src = a.dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
-        }
-      }
-    }
-
-    if (MODE == 0) {
-      // wave reduction, one atomic per wave
-      for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
-      if ((tid & 63) == 0 && n_flag) atomicAdd(t.is_def ? &c.state[t.page].n_nulls : &c.state[t.page].n_rows, n_flag);
-    } else {
-      if (bad_index) set_status(&c.state[t.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
-    }
   }
 }
 
@@ -833,26 +500,6 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, hipStream_t s
   return hipGetLastError();
 }
 
-static int clamp_stage(int stage_bytes) {
-  int sb = (stage_bytes + 15) / 16 * 16;
-  if (sb < 1024) sb = 1024;
-  if (sb > kStageMax) sb = kStageMax;
-  return sb;
-}
-
-hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
-                                int stage_bytes, int32_t *rep_out, int32_t *def_out, hipStream_t stream) {
-  if (n_tiles <= 0) return hipSuccess;
-  ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.n_streams = 2 * c.nd; a.stream0 = 0; a.n_tiles = n_tiles;
-  a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.dict_lds = 0; a.values_out = nullptr;
-  a.stage_bytes = clamp_stage(stage_bytes);
-  int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
-  size_t shmem = kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
-  hipLaunchKernelGGL((k_hybrid_expand<0, false>), dim3(grid), dim3(256), shmem, stream, a);
-  return hipGetLastError();
-}
-
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream) {
   hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(1024), 0, stream, c, out);
   return hipGetLastError();
@@ -861,38 +508,6 @@ hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t st
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream) {
   hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(1024), 0, stream, c, totals);
   return hipGetLastError();
-}
-
-hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
-                              int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, int n_cu,
-                              hipStream_t stream) {
-  if (n_tiles <= 0) return hipSuccess;
-  ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.n_streams = c.nd; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
-  a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out;
-  a.stage_bytes = clamp_stage(stage_bytes);
-  const size_t run_bytes = kRunLdsBytes + kSegLdsBytes + a.stage_bytes;
-  const size_t dict_bytes = ((size_t)dict_n * c.elem_size + 15) / 16 * 16;
-  // dictionaries up to 48 KiB are staged in LDS (three 256-thread blocks per CU keep 160 KiB of LDS busy);
-  // larger ones are gathered from L2 / HBM
-  a.dict_lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;
-  size_t shmem = run_bytes + (a.dict_lds ? dict_bytes : 0);
-  int per_cu = (int)(160 * 1024 / (shmem + 512));
-  if (per_cu > 8) per_cu = 8;
-  if (per_cu < 1) per_cu = 1;
-  int grid = n_cu * per_cu;
-  if (grid > n_tiles) grid = n_tiles;
-  auto go = [&](auto kern) -> hipError_t {
-    if (shmem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, a);
-    return hipGetLastError();
-  };
-  if (c.elem_size == 4) return a.dict_lds ? go(&k_hybrid_expand<4, true>) : go(&k_hybrid_expand<4, false>);
-  if (c.elem_size == 8) return a.dict_lds ? go(&k_hybrid_expand<8, true>) : go(&k_hybrid_expand<8, false>);
-  return a.dict_lds ? go(&k_hybrid_expand<1, true>) : go(&k_hybrid_expand<1, false>);
 }
 
 }  // namespace pqd

@@ -78,7 +78,7 @@ struct pqd_handle {
   int n_cu = 256;
   bool profiling = false;
 
-  DevBuf in, meta, runs, tile_run, dict, values, dense, def, rep, offsets, bytes, scratch, small;
+  DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
   int64_t bytes_len = 0;
   PinnedBuf stage_in, stage_meta, host_small;
@@ -267,6 +267,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   // ---- workspaces and outputs ----
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
   if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
+  if ((rc = h->tile_desc.ensure(sizeof(TileDesc) * ((size_t)std::max(tp_levels.back(), tp_dict.back()) + 1)))) return rc;
   const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
   const bool nullable = col->max_def > 0;
   if (!is_bytes) {
@@ -334,7 +335,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
       { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
-        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
+        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
@@ -353,7 +354,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
         { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
         { Prof pf(h, "k_hybrid_expand<dict>");
           HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
-                                     reinterpret_cast<uint8_t *>(pairs), h->n_cu, h->stream)); }
+                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
       }
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, -1, pairs, h->stream)); }
@@ -416,7 +417,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     else {
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<dict>");
-        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->n_cu, h->stream)); }
+        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
   }
   if (any_plain) {
@@ -523,7 +524,7 @@ int pqd_handle_destroy(pqd_handle *h) {
   for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
                     &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
-                    &h->doff, &h->dict_pairs};
+                    &h->doff, &h->dict_pairs, &h->tile_desc};
   for (DevBuf *b : bufs) b->release();
   h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);

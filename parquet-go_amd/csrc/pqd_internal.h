@@ -56,10 +56,33 @@ struct Stream {
 };
 
 // Run-table entry: x = out_start | (bit_packed << 31); y = RLE value, or byte offset of the packed
-// payload inside the stream.  The entry after a stream's last run holds the end position.
-struct RunEntry {
+// payload inside the stream; z = work items of all earlier runs of the stream, an item being up to eight
+// consecutive values of one run (a run of n values has ceil(n / 8) items; a bit-packed item is one group of
+// w bytes).  The entry after a stream's last run holds the end position and the item total.
+struct __attribute__((aligned(16))) RunEntry {
   uint32_t x;
   uint32_t y;
+  uint32_t z;
+  uint32_t spare;
+};
+
+// Everything a block needs to expand one tile (kTile consecutive values of one hybrid stream), precomputed
+// by one thread per tile so that the expanding block starts its loads after a single 64-byte read.
+struct __attribute__((aligned(64))) TileDesc {
+  int64_t in_off;     // chunk offset of stream byte 0
+  int64_t out_elem;   // output element index of the stream's value 0
+  int64_t run0;       // run-table index of the first run of the slice
+  uint32_t item_lo;   // first work item of the tile (stream-wide numbering)
+  int32_t n_items;
+  int32_t t0, t1;     // values [t0, t1) of the stream
+  int32_t org;        // stream position of the first staged byte (16-byte aligned in memory)
+  int32_t span;       // bytes from org the tile can touch
+  int32_t nr;         // slice entries (runs of the tile + the entry after them)
+  int32_t avail;      // stream bytes that exist
+  int32_t w;
+  int32_t flags;      // bit 0: valid, bit 1: slice and bytes fit the LDS budget, bit 2: definition levels
+  int32_t page;
+  int32_t pad;
 };
 
 struct ChunkCtx {

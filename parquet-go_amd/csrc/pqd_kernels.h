@@ -13,13 +13,14 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, hipStream_t s
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)
 hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
-                                int stage_bytes, int32_t *rep_out, int32_t *def_out, hipStream_t stream);
+                                int stage_bytes, int32_t *rep_out, int32_t *def_out, TileDesc *descs, int n_cu,
+                                hipStream_t stream);
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream);
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream);
 // dictionary indices -> gathered values
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
-                              int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, int n_cu,
-                              hipStream_t stream);
+                              int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
+                              int n_cu, hipStream_t stream);
 
 // ---- k_plain.hip ----
 hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream);

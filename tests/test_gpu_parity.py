@@ -93,6 +93,29 @@ def test_dict_large_dictionary_global_gather(dec, oracle):
     check_same(dec, oracle, chunk, pages, pg.INT32)
 
 
+@pytest.mark.parametrize("ptype,nd,w", [(pg.INT32, 20000, 15), (pg.INT32, 40000, 16), (pg.INT64, 9000, 14), (pg.INT64, 30000, 15),
+                                         (pg.DOUBLE, 70000, 17), (pg.INT32, 300000, 19), (pg.INT96, 9000, 14)])
+def test_dict_mid_and_large_dictionaries(dec, oracle, ptype, nd, w):
+    # dictionaries between 48 KiB and 1 MiB take the kernel variant that keeps the head of the dictionary in LDS
+    # and gathers the rest from memory; beyond that (and for 12-byte entries) everything is gathered from memory
+    rng = np.random.default_rng(500 + nd)
+    cb = pg.ChunkBuilder(gap=3)
+    cb.dict_page(rand_dict(rng, ptype, nd), nd)
+    for n, style in ((70000, "mixed"), (9001, "bp"), (300, "rle"), (50000, "arrow")):
+        idx = rng.integers(0, nd, n)
+        idx[rng.integers(0, n, 5)] = nd - 1
+        idx[rng.integers(0, n, 5)] = 0
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(idx, w, rng, style))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype)
+    assert o.status == 0
+    # an index just past the end, in the part served from memory
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 16, pg.dict_indices_body(np.array([1, 2, nd, 3] * 4), w + 1, rng, "bp"))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype)
+    assert o.status == oracle.PANIC
+
+
 def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
     # what the reference's own writer emits: width 32, RLE runs only (layout/dictpage.go:155-158), 8 KiB pages
     rng = np.random.default_rng(10)
@@ -275,6 +298,23 @@ def test_truncated_bit_packed_run_is_zero_filled(dec, oracle):
     chunk, pages = cb.finish()
     g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
     assert o.status == 0
+
+
+@pytest.mark.parametrize("w", [1, 5, 12, 20])
+def test_bit_packed_payload_cut_far_short(dec, oracle, w):
+    # headers announce long bit-packed runs but the page ends after a fraction of the payload: everything the
+    # missing bytes would have held decodes as index 0 (encodingread.go:188-191), over many tiles
+    rng = np.random.default_rng(90 + w)
+    nd = min(1 << w, 3000)
+    cb = pg.ChunkBuilder(gap=1)
+    cb.dict_page(rng.integers(-2**31, 2**31 - 1, nd, dtype=np.int32).tobytes(), nd)
+    n = 40000
+    idx = rng.integers(0, nd, n)
+    body = pg.dict_indices_body(idx, w, style="bp")
+    for keep in (0.9, 0.31, 0.02):
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, body[:max(3, int(len(body) * keep))])
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
 
 
 def test_device_resident_entry_point(dec, oracle):
