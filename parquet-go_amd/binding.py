@@ -53,7 +53,8 @@ class DecodeError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libpqdecode.so")
+    """The in-tree build; PQD_LIB points tests and benches at another build of the same library."""
+    return os.environ.get("PQD_LIB") or os.path.join(_HERE, "lib", "libpqdecode.so")
 
 
 def lib():

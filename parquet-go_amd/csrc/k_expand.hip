@@ -5,6 +5,7 @@
 // Reference behaviour reproduced here: encoding/encodingread.go:146-167 (RLE run), :170-228 (bit-packed run),
 // layout/page.go:139-164 (dictionary gather), :835-888 (levels, null count), :925-927 (row count).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pqd_kernels.h"
 
 namespace pqd {
@@ -15,6 +16,9 @@ struct U32x4Unaligned { uint32_t v[4]; } __attribute__((packed));
 struct U64x2Unaligned { uint64_t v[2]; } __attribute__((packed));
 struct U64Unaligned { uint64_t v; } __attribute__((packed));
 
+#ifndef PQD_EXP
+#define PQD_EXP 0  // experiment switches for timing studies (results are wrong when non-zero)
+#endif
 constexpr int kSegBytes = 128;  // run index of the first item of every 64-item segment of a tile (32 entries)
 
 struct ExpandArgs {
@@ -236,7 +240,7 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       s_mark[q] = 0;  // left clean for the next tile
       r = r > m ? r : m;
     }
-    r = wave_incl_max(r);
+    if (!(PQD_EXP & 8)) r = wave_incl_max(r);
     if (!active) continue;
     const RunEntry e = s_runs[r];
     const int next_rel = (int)(s_runs[r + 1].x & 0x7FFFFFFFu) - d.t0;
@@ -249,7 +253,9 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
     const bool bp = e.x >> 31;
     if (bp) {
       const uint32_t rel = e.y - (uint32_t)d.org + kk * (uint32_t)W;
-      if (rel + (uint32_t)W + 8u <= staged) {
+      if ((PQD_EXP & 4) != 0) {
+        for (int j = 0; j < 8; j++) x[j] = (kk + j) & 1u;
+      } else if (rel + (uint32_t)W + 8u <= staged) {
         unpack8<W>(s_stage, rel, x);
       } else {
         // a payload cut short by the end of the stream: bytes that are not there read as zero
@@ -277,8 +283,8 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       if (MODE == 4) {
         uint32_t y[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
-        store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
+        for (int j = 0; j < 8; j++) y[j] = (PQD_EXP & 2) ? x[j] : dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
+        if (!(PQD_EXP & 1) || y[0] == 0x12345u) store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
       } else {
         uint64_t y[8];
 #pragma unroll
@@ -389,13 +395,17 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
     int n_flag = 0;  // levels: nulls or rows counted by this thread
     bool bad_index = false;
     if (in_lds) {
-      switch (__builtin_amdgcn_readfirstlane(d.w)) {
+      switch ((PQD_EXP & 16) ? 99 : __builtin_amdgcn_readfirstlane(d.w)) {
+#ifdef PQD_ONLY_W
+        case PQD_ONLY_W: expand_items<MODE, DMODE, GT, PQD_ONLY_W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
+#else
 #define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
         PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
         PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
         PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
         PQD_CASE(25) PQD_CASE(26) PQD_CASE(27) PQD_CASE(28) PQD_CASE(29) PQD_CASE(30) PQD_CASE(31) PQD_CASE(32)
 #undef PQD_CASE
+#endif
         default: break;
       }
     } else if (valid) {
@@ -485,7 +495,7 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
 
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, hipStream_t stream) {
+                              int n_cu, bool shared_gpu, hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   ExpandArgs a;
   a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
@@ -494,7 +504,12 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   const size_t dict_bytes = ((size_t)dict_n * esz + 15) / 16 * 16;
   const bool fixed48 = esz == 4 || esz == 8;
 
-  if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024) {
+  // shared_gpu: other chunks are being decoded at the same time.  The variant below that keeps the head of a
+  // mid-size dictionary in LDS takes a whole CU per workgroup and so shuts the other chunks' kernels out; with
+  // company the plain gather is the better neighbour.
+  static const char *force = std::getenv("PQD_SPLIT");  // "0" / "1": pin the choice (tests)
+  const bool no_split = force ? force[0] == '0' : shared_gpu;
+  if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024 || no_split) {
     // small dictionaries: whole dictionary in the LDS of every block, several 256-thread blocks per CU.
     // Large ones of other element sizes, and very large ones: gathered from L2 / HBM.
     const bool lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;

@@ -494,8 +494,9 @@ hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, hipStream_t stream) {
+hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
+  if (wide) return launch_hybrid_prescan_wide(c, s0, n, stream);
   hipLaunchKernelGGL(k_hybrid_prescan, dim3(n), dim3(64), 0, stream, c, s0);
   return hipGetLastError();
 }

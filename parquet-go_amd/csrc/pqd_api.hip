@@ -5,7 +5,9 @@
 // -> Table.Merge (layout/table.go:52-71).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -133,6 +135,11 @@ int elem_size_of(const pqd_column_desc &c) {
     default: return 0;
   }
 }
+
+// Handles with a decode in flight (submitted, not yet waited for), over the whole process.  A chunk decoded while
+// others are in flight gets the kernel variants that leave most of each CU to them; a lone chunk gets the ones
+// that use the whole GPU to cut its latency.
+std::atomic<int> g_inflight{0};
 
 bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY; }
 
@@ -329,11 +336,22 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     stage_dict = (int)(bpv * kTile * 1.25) + 512;
   }
 
+  // Few long streams: a workgroup per stream takes the decoding off the serial header walk.  Many short ones
+  // (small pages): a wavefront per stream keeps more of them in flight.
+  int64_t data_bytes = 0;
+  for (int p = 0; p < n_pages; p++) if (h->h_pages[(size_t)p].data_idx >= 0) data_bytes += h->h_pages[(size_t)p].body_len;
+  const char *force = std::getenv("PQD_PRESCAN");  // "wide" / "wave": pin the choice (tests)
+  const bool shared_gpu = g_inflight.load(std::memory_order_relaxed) - (h->busy ? 1 : 0) >= 2;
+  bool wide_dict = !shared_gpu && nd > 0 && nd <= 4 * h->n_cu && data_bytes / nd >= 64 * 1024;
+  bool wide_levels = wide_dict && slots / nd >= 256 * 1024;
+  if (force && force[0] == 'w' && force[1] == 'i') wide_dict = wide_levels = true;
+  if (force && force[0] == 'w' && force[1] == 'a') wide_dict = wide_levels = false;
+
   // ---- kernels ----
   if (n_pages > 0) {
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
-      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
         HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
@@ -351,10 +369,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if (any_dict_enc) {
       if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
       else {
-        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
+        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
         { Prof pf(h, "k_hybrid_expand<dict>");
           HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
-                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
+                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu, h->stream)); }
       }
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, -1, pairs, h->stream)); }
@@ -415,9 +433,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (any_dict_enc) {
     if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
     else {
-      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<dict>");
-        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
+        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu, h->stream)); }
     }
   }
   if (any_plain) {
@@ -457,6 +475,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   h->result = pqd_chunk_result{};
   h->result.status = host_status;
   h->result.bad_page = host_bad;
+  if (!h->busy) g_inflight.fetch_add(1, std::memory_order_relaxed);
   h->busy = true;
   return PQD_OK;
 }
@@ -520,6 +539,7 @@ int pqd_handle_create(int device, void *stream, pqd_handle **out) {
 int pqd_handle_destroy(pqd_handle *h) {
   if (!h) return PQD_OK;
   Guard g(h->device);
+  if (h->busy) { h->busy = false; g_inflight.fetch_sub(1, std::memory_order_relaxed); }
   (void)hipStreamSynchronize(h->stream);
   for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
@@ -564,8 +584,9 @@ int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
   if (!h) return fail_arg("handle is NULL");
   Guard g(h->device);
   if (h->busy) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
     h->busy = false;
+    g_inflight.fetch_sub(1, std::memory_order_relaxed);
+    HIP_TRY(hipStreamSynchronize(h->stream));
     const int64_t *tot = static_cast<const int64_t *>(h->host_small.p);
     const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + 16;
     pqd_chunk_result &r = h->result;

@@ -9,7 +9,9 @@ namespace pqd {
 // ---- k_hybrid.hip ----
 hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream);
 // streams [s0, s0 + n): one wavefront walks the run headers of each stream
-hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, hipStream_t stream);
+// wide: one 576-thread workgroup per stream (few long streams) instead of one wavefront per stream
+hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, hipStream_t stream);
+hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)
 hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
@@ -20,7 +22,7 @@ hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t st
 // dictionary indices -> gathered values
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, hipStream_t stream);
+                              int n_cu, bool shared_gpu, hipStream_t stream);
 
 // ---- k_plain.hip ----
 hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream);

@@ -29,10 +29,11 @@ def my_chunks(byte_sizes, rank, world):
     return assign_chunks(byte_sizes, world)[rank]
 
 
-def timed_region(step, steps, warmup, sync=None, dist=None, device=None):
+def timed_region(step, steps, warmup, sync=None, dist=None, device=None, drain=None):
     """Runs `step()` warmup + steps times; the timed part is bracketed by barrier + device sync on both sides and
     the result is the MAX over ranks (seconds).  `sync` waits for the local device; `dist` is torch.distributed
-    when a process group is up, else None."""
+    when a process group is up, else None.  `drain` completes work the steps left in flight (it runs inside the
+    timed part, before the closing device sync)."""
     import torch
 
     def fence():
@@ -43,10 +44,14 @@ def timed_region(step, steps, warmup, sync=None, dist=None, device=None):
 
     for _ in range(warmup):
         step()
+    if drain is not None and warmup:
+        drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if drain is not None:
+        drain()
     if sync is not None:
         sync()
     fence()
