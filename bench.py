@@ -211,14 +211,23 @@ def main():
     for (w, name), (ms, n) in ktimes.items():
         all_ms[name] = all_ms.get(name, 0.0) + ms
     per_width, achieved, avg_ms = expand_stats(ktimes)
+    exp_total_ms = sum(ms for (w, name), (ms, n) in ktimes.items() if name == "k_hybrid_expand<dict>")
+    exp_total_bytes = sum((item["in_bytes"] + n_values * 4 + item["dict_n"] * 4) * ktimes.get((item["w"], "k_hybrid_expand<dict>"), (0, 0))[1]
+                          for item in work)
+    in_flight = exp_total_ms / (elapsed * 1e3) if elapsed else 0.0
+    aggregate = exp_total_bytes / elapsed / 1e9 if elapsed else 0.0
     iso_pw, iso_gbps, iso_avg = expand_stats(iso)
     roofline = {"bound": "hbm", "kernel": "k_hybrid_expand<dict> (bit unpack + dictionary gather)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args, widths),
                 "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "per_width": per_width,
-                "note": "durations from HIP events on each handle's stream inside the timed region, where %d chunks are "
-                        "in flight and their kernels share the CUs; 'isolated' is the same launch with the GPU to itself"
-                        % n_handles,
+                "note": "durations from HIP events on each handle's stream inside the timed region, where %d chunks are in "
+                        "flight and on average 'mean_in_flight' launches of this kernel are resident at once, each holding a "
+                        "share of the CUs for that much longer; 'aggregate' = algorithmic bytes of all its launches / "
+                        "elapsed time of the region; 'isolated' is the same launch with the GPU to itself"
+                        % (n_handles * depth),
+                "mean_in_flight": round(in_flight, 2),
+                "aggregate": {"achieved": round(aggregate, 1), "frac": round(aggregate / HBM_PEAK_GBPS, 4)},
                 "isolated": {"achieved": round(iso_gbps, 1), "frac": round(iso_gbps / HBM_PEAK_GBPS, 4),
                              "avg_launch_ms": round(iso_avg, 4) if iso_avg else None, "per_width": iso_pw},
                 "kernel_ms_share": {k: round(v / max(sum(all_ms.values()), 1e-9), 4) for k, v in all_ms.items()}}

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,6 +97,8 @@ struct pqd_handle {
   pqd_chunk_result result{};
   ChunkCtx ctx{};
 
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;  // hand-over to and from the device's shared stream
+
   std::vector<KernelEvent> events;   // pool
   size_t n_events = 0;               // used by the last call
 };
@@ -111,7 +114,8 @@ struct Guard {
 struct Prof {
   pqd_handle *h;
   KernelEvent *ev = nullptr;
-  Prof(pqd_handle *hh, const char *name) : h(hh) {
+  hipStream_t st;
+  Prof(pqd_handle *hh, const char *name, hipStream_t on = nullptr) : h(hh), st(on ? on : hh->stream) {
     if (!h->profiling) return;
     if (h->n_events == h->events.size()) {
       KernelEvent e{name, nullptr, nullptr};
@@ -120,9 +124,9 @@ struct Prof {
     }
     ev = &h->events[h->n_events++];
     ev->name = name;
-    (void)hipEventRecord(ev->start, h->stream);
+    (void)hipEventRecord(ev->start, st);
   }
-  ~Prof() { if (ev) (void)hipEventRecord(ev->stop, h->stream); }
+  ~Prof() { if (ev) (void)hipEventRecord(ev->stop, st); }
 };
 
 int elem_size_of(const pqd_column_desc &c) {
@@ -140,6 +144,40 @@ int elem_size_of(const pqd_column_desc &c) {
 // others are in flight gets the kernel variants that leave most of each CU to them; a lone chunk gets the ones
 // that use the whole GPU to cut its latency.
 std::atomic<int> g_inflight{0};
+
+// Optional shared streams per device for the bandwidth-bound expansion kernels (PQD_HEAVY_LANES = 1..4): every
+// handle walks run headers on its own stream and hands the expansion over to a shared one, so that at most that
+// many expansions are resident at once and each runs close to its stand-alone speed.  Off by default: on MI355X
+// letting all expansions share the GPU freely finishes a batch of chunks about 20 % sooner, at the price of
+// per-kernel durations that say little (each kernel holds a fraction of the CUs for several times its
+// stand-alone duration).
+std::mutex g_heavy_mu;
+constexpr int kMaxLanes = 4;
+hipStream_t g_heavy[64][kMaxLanes] = {};
+std::atomic<unsigned> g_heavy_next{0};
+
+// PQD_HEAVY_LANES: shared streams per device (0: none, every handle expands on its own stream)
+int heavy_lanes() {
+  static const int n = [] {
+    const char *e = std::getenv("PQD_HEAVY_LANES");
+    int v = e ? std::atoi(e) : 0;
+    return v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
+  }();
+  return n;
+}
+
+hipStream_t heavy_stream(int device) {
+  const int lanes = heavy_lanes();
+  if (device < 0 || device >= 64 || lanes == 0) return nullptr;
+  const int lane = (int)(g_heavy_next.fetch_add(1, std::memory_order_relaxed) % (unsigned)lanes);
+  std::lock_guard<std::mutex> lk(g_heavy_mu);
+  if (!g_heavy[device][lane]) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    g_heavy[device][lane] = s;
+  }
+  return g_heavy[device][lane];
+}
 
 bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY; }
 
@@ -347,6 +385,20 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (force && force[0] == 'w' && force[1] == 'i') wide_dict = wide_levels = true;
   if (force && force[0] == 'w' && force[1] == 'a') wide_dict = wide_levels = false;
 
+  // hand-over of the dictionary expansion to the device's shared stream and back
+  hipStream_t heavy = heavy_stream(h->device);
+  if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
+  auto to_heavy = [&]() -> hipError_t {
+    if (heavy == h->stream) return hipSuccess;
+    hipError_t e = hipEventRecord(h->ev_ready, h->stream);
+    return e != hipSuccess ? e : hipStreamWaitEvent(heavy, h->ev_ready, 0);
+  };
+  auto from_heavy = [&]() -> hipError_t {
+    if (heavy == h->stream) return hipSuccess;
+    hipError_t e = hipEventRecord(h->ev_done, heavy);
+    return e != hipSuccess ? e : hipStreamWaitEvent(h->stream, h->ev_done, 0);
+  };
+
   // ---- kernels ----
   if (n_pages > 0) {
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
@@ -370,9 +422,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
       else {
         { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
-        { Prof pf(h, "k_hybrid_expand<dict>");
+        HIP_TRY(to_heavy());
+        { Prof pf(h, "k_hybrid_expand<dict>", heavy);
           HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
-                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu, h->stream)); }
+                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu && heavy == h->stream, heavy)); }
+        HIP_TRY(from_heavy());
       }
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, -1, pairs, h->stream)); }
@@ -434,8 +488,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
     else {
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
-      { Prof pf(h, "k_hybrid_expand<dict>");
-        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu, h->stream)); }
+      HIP_TRY(to_heavy());
+      { Prof pf(h, "k_hybrid_expand<dict>", heavy);
+        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out,
+                                   static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu && heavy == h->stream, heavy)); }
+      HIP_TRY(from_heavy());
     }
   }
   if (any_plain) {
@@ -530,6 +587,8 @@ int pqd_handle_create(int device, void *stream, pqd_handle **out) {
     if (e != hipSuccess) { delete h; return fail_hip(e, "hipStreamCreate"); }
     h->own_stream = true;
   }
+  if (hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess) h->ev_ready = nullptr;
+  if (hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) h->ev_done = nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   *out = h;
@@ -542,6 +601,8 @@ int pqd_handle_destroy(pqd_handle *h) {
   if (h->busy) { h->busy = false; g_inflight.fetch_sub(1, std::memory_order_relaxed); }
   (void)hipStreamSynchronize(h->stream);
   for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_done) (void)hipEventDestroy(h->ev_done);
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
                     &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
                     &h->doff, &h->dict_pairs, &h->tile_desc};
