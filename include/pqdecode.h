@@ -136,6 +136,15 @@ int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_
 int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages,
                             int32_t n_pages, const pqd_column_desc *col);
 
+/* Levels only: repetition / definition levels, null and row counts of every page, values left undecoded.
+ * What ColumnBufferType.SkipRows needs to find a row boundary (reader/columnbuffer.go:158-230,
+ * layout.ReadPageRawData + Page.GetRLDLFromRawData, layout/page.go:433-559).  Results as for pqd_decode_chunk
+ * with no values / offsets / bytes (pqd_copy_out rejects those pointers, pqd_result_device returns NULL). */
+int pqd_decode_levels(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages,
+                      int32_t n_pages, const pqd_column_desc *col);
+int pqd_decode_levels_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages,
+                             int32_t n_pages, const pqd_column_desc *col);
+
 /* Wait for the handle's stream and collect status and totals. */
 int pqd_wait(pqd_handle *h, pqd_chunk_result *res);
 
@@ -146,6 +155,14 @@ int pqd_result_device(pqd_handle *h, pqd_device_result *out);
  * zeros when the column has no such levels, as the reference's Table holds them. */
 int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_levels, int64_t *offsets,
                  uint8_t *bytes);
+
+/* Row index of the last decoded chunk: entry r = slot at which row r begins (a slot with repetition level 0; every
+ * slot when max_rep is 0), entry num_rows = num_slots.  With it the caller cuts the typed arrays at row boundaries
+ * the way Table.Pop does (layout/table.go:73-103: the first n rows are the slots before the (n+1)-th slot with
+ * repetition level 0) and ColumnBufferType.ReadRows hands rows out (reader/columnbuffer.go:232-262).
+ * host_out: num_rows + 1 entries (cap says how many fit) or NULL; device_out: receives the device array or NULL.
+ * The device array is owned by the handle and valid until its next decode call. */
+int pqd_row_starts(pqd_handle *h, int64_t *host_out, int64_t cap, int64_t **device_out);
 
 /* Per-page (numNulls, numRows, numValues) of the last decoded chunk, 3 x int64 per page in page order
  * (dictionary pages report zeros). */

@@ -214,6 +214,58 @@ def read_chunk(chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0)
     return out
 
 
+def table_pop(rep_levels, num_rows):
+    """layout/table.go:73-103: number of leading slots Table.Pop(numRows) hands out (the loop, literally)."""
+    num = -1
+    i = 0
+    ln = len(rep_levels)
+    while i < ln:
+        if rep_levels[i] == 0:
+            num += 1
+            if num >= num_rows:
+                break
+        i += 1
+    return i
+
+
+class ColumnBufferModel:
+    """reader/columnbuffer.go:105-156, :232-262 over oracle tables, one ReadPage batch per chunk: DataTable as growing
+    arrays, DataTableNumRows one below the row starts seen until the end of the file, ReadRows = Pop."""
+
+    def __init__(self, tables):
+        self.tables = list(tables)      # decoded chunks (Table), in order
+        self.k = 0
+        self.rep = np.zeros(0, np.int32)
+        self.dl = np.zeros(0, np.int32)
+        self.num_rows = -1              # columnbuffer.go:44
+        self.eof = False
+
+    def _read(self):
+        if self.k >= len(self.tables):
+            if not self.eof:
+                self.eof = True
+                self.num_rows += 1      # columnbuffer.go:58
+            return False
+        t = self.tables[self.k]
+        self.k += 1
+        self.rep = np.concatenate([self.rep, t.rep_levels])
+        self.dl = np.concatenate([self.dl, t.def_levels])
+        self.num_rows += t.n_rows
+        return True
+
+    def read_rows(self, num):
+        """-> (slots handed out, rows handed out)"""
+        while self.num_rows < num and self._read():
+            pass
+        if self.num_rows < 0:
+            self.num_rows = 0
+        num = min(num, self.num_rows)
+        end = table_pop(self.rep, num)
+        self.rep, self.dl = self.rep[end:], self.dl[end:]
+        self.num_rows -= num
+        return end, num
+
+
 def read_chunk_timed(chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0):
     """Decode and discard (no copies back to numpy): used for CPU-baseline timing.  -> (rc, n_slots)"""
     a = _as_u8(chunk)

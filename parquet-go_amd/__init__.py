@@ -11,3 +11,4 @@ from .binding import (  # noqa: F401
     ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY, ENC_RLE_DICTIONARY, ENC_BYTE_STREAM_SPLIT,
     DATA_PAGE, INDEX_PAGE, DICTIONARY_PAGE, DATA_PAGE_V2,
 )
+from .columnbuffer import ColumnBuffer, RowSlice  # noqa: F401,E402

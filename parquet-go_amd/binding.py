@@ -22,7 +22,7 @@ EXPORTS = [
     "pqd_version", "pqd_last_error", "pqd_strerror", "pqd_device_count", "pqd_handle_create",
     "pqd_handle_destroy", "pqd_set_profiling", "pqd_scan_pages", "pqd_decode_chunk",
     "pqd_decode_chunk_device", "pqd_wait", "pqd_result_device", "pqd_copy_out", "pqd_page_counts",
-    "pqd_kernel_times",
+    "pqd_kernel_times", "pqd_decode_levels", "pqd_decode_levels_device", "pqd_row_starts",
 ]
 
 
@@ -76,6 +76,9 @@ def lib():
         L.pqd_scan_pages.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.pqd_decode_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_chunk_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
+        L.pqd_decode_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
+        L.pqd_decode_levels_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
+        L.pqd_row_starts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.pqd_wait.argtypes = [C.c_void_p, C.POINTER(_ChunkResult)]
         L.pqd_result_device.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
         L.pqd_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -179,6 +182,12 @@ class Decoder:
         _check(lib().pqd_result_device(self._h, C.byref(d)))
         return d
 
+    def row_starts(self, r):
+        """Slot index of every row start of the last decoded chunk + end marker (int64[num_rows + 1])."""
+        out = np.zeros(r.num_rows + 1, np.int64)
+        _check(lib().pqd_row_starts(self._h, C.c_void_p(out.ctypes.data), out.size, None))
+        return out
+
     def kernel_times(self):
         arr = (_KernelTime * 32)()
         n = C.c_int32(0)
@@ -218,6 +227,30 @@ class Decoder:
         return t
 
     _is_bytes = False
+
+    def decode_levels(self, chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0):
+        """Skip path: levels and counts only -> Table with kind 'levels' (no values)."""
+        a = np.frombuffer(chunk, dtype=np.uint8) if not isinstance(chunk, np.ndarray) else np.ascontiguousarray(chunk, np.uint8)
+        pg = np.ascontiguousarray(pages, dtype=PAGE_DESC_DTYPE)
+        self._pages, self._keep = pg, a
+        cd = self._col(physical_type, type_length, max_def, max_rep)
+        _check(lib().pqd_decode_levels(self._h, C.c_void_p(a.ctypes.data if a.size else None), a.size,
+                                       C.c_void_p(pg.ctypes.data if pg.size else None), pg.size, C.byref(cd)))
+        r = self.wait()
+        t = Table()
+        t.status, t.bad_page, t.kind = r.status, r.bad_page, "levels"
+        if r.status != 0:
+            return t
+        n = r.num_slots
+        t.n_slots, t.n_rows, t.n_nulls, t.n_values = n, r.num_rows, r.num_nulls, r.num_values
+        t.def_levels = np.zeros(n, np.int32)
+        t.rep_levels = np.zeros(n, np.int32)
+        _check(lib().pqd_copy_out(self._h, None, C.c_void_p(t.def_levels.ctypes.data), C.c_void_p(t.rep_levels.ctypes.data), None, None))
+        if pg.size:
+            pc = np.zeros((pg.size, 3), np.int64)
+            _check(lib().pqd_page_counts(self._h, C.c_void_p(pc.ctypes.data), pg.size))
+            t.page_counts = pc
+        return t
 
     def decode(self, chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0):
         """submit + wait + fetch."""

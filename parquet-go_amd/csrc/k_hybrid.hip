@@ -63,7 +63,10 @@ __global__ void k_page_setup(ChunkCtx c) {
   }
   int64_t pos = pi.body_off, end = pi.body_off + pi.body_len;
   const int64_t nv = pi.num_values;
-  int status = PQD_OK;
+  // status: what goes wrong up to and including the framing of the repetition levels; def_status: the framing of
+  // the definition levels.  Kept apart because the reference decodes the repetition levels completely before it
+  // looks at the definition levels (layout/page.go:835-881): an error inside the repetition level runs comes first.
+  int status = PQD_OK, def_status = PQD_OK;
   if (nv < 0) status = PQD_ERR_MALFORMED;
   if (status == PQD_OK && nv > 0) {  // with num_values == 0 ReadDataPageValues returns before reading anything
     if (pi.page_type == PQD_DATA_PAGE) {
@@ -73,7 +76,7 @@ __global__ void k_page_setup(ChunkCtx c) {
         rs.cnt = (int32_t)nv;
       }
       if (status == PQD_OK && c.max_def > 0) {
-        status = take_prefixed_v1(c.in, pos, end, ds);
+        def_status = take_prefixed_v1(c.in, pos, end, ds);
         ds.w = bit_len32((uint32_t)c.max_def);
         ds.cnt = (int32_t)nv;
       }
@@ -90,7 +93,7 @@ __global__ void k_page_setup(ChunkCtx c) {
           rs.w = bit_len32((uint32_t)c.max_rep); rs.cnt = (int32_t)nv;
         }
         if (c.max_def > 0) {
-          if (dll == 0 && status == PQD_OK) status = PQD_ERR_MALFORMED;
+          if (dll == 0) def_status = PQD_ERR_MALFORMED;
           ds.off = pos + rll; ds.len = (int32_t)dll; ds.avail = (int32_t)dll;
           ds.w = bit_len32((uint32_t)c.max_def); ds.cnt = (int32_t)nv;
         }
@@ -101,7 +104,9 @@ __global__ void k_page_setup(ChunkCtx c) {
   ps.status = status;
   ps.val_off = pos;
   ps.val_len = end - pos;
-  rs.status = ds.status = vs.status = status;
+  rs.status = status;
+  ds.status = status != PQD_OK ? status : def_status;
+  vs.status = ds.status;
   c.streams[d] = rs;
   c.streams[c.nd + d] = ds;
   c.streams[2 * c.nd + d] = vs;

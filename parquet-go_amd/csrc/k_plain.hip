@@ -273,6 +273,53 @@ __global__ __launch_bounds__(256) void k_scatter_apply(const int32_t *def, int64
   }
 }
 
+// ---- row index: out[r] = slot of the r-th entry with repetition level 0 (layout/table.go:73-103 cuts rows there) ----
+__global__ __launch_bounds__(256) void k_row_starts(const int32_t *rep, int64_t n, const int64_t *partial, int64_t *out,
+                                                    int64_t n_rows) {
+  __shared__ int s_wave[4];
+  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t s0 = base + (int64_t)tid * 16;
+  uint32_t first = 0;
+  for (int j = 0; j < 16; j++)
+    if (s0 + j < n && (rep == nullptr || rep[s0 + j] == 0)) first |= 1u << j;
+  const int c = __builtin_popcount(first);
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int q = 0; q < wv; q++) wbase += s_wave[q];
+  int64_t rank = partial[blockIdx.x] + wbase + incl - c;
+  for (int j = 0; j < 16; j++)
+    if ((first >> j) & 1u) out[rank++] = s0 + j;
+  if (blockIdx.x == 0 && tid == 0) out[n_rows] = n;  // end marker
+}
+
+__global__ __launch_bounds__(256) void k_iota(int64_t *out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (int64_t)gridDim.x * 256) out[i] = i;
+}
+
+hipError_t launch_row_starts(const int32_t *rep_levels, int64_t n_slots, int64_t n_rows, int64_t *scratch, int64_t *out,
+                             hipStream_t stream) {
+  if (rep_levels == nullptr) {  // flat column: every slot is a row
+    hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, stream, out, n_slots);
+    return hipGetLastError();
+  }
+  const int n_tiles = (int)((n_slots + kScatterTile - 1) / kScatterTile);
+  if (n_tiles <= 0) {
+    hipLaunchKernelGGL(k_row_starts, dim3(1), dim3(256), 0, stream, rep_levels, (int64_t)0, scratch, out, n_rows);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_scatter_count, dim3(n_tiles), dim3(256), 0, stream, rep_levels, n_slots, 0, scratch);
+  hipLaunchKernelGGL(k_scatter_scan, dim3(1), dim3(1024), 0, stream, scratch, n_tiles);
+  hipLaunchKernelGGL(k_row_starts, dim3(n_tiles), dim3(256), 0, stream, rep_levels, n_slots, scratch, out, n_rows);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream) {
   hipLaunchKernelGGL(k_dict_plain_fixed, dim3(16), dim3(256), 0, stream, c, dict_page, dict_out);

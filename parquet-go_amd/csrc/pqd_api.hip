@@ -83,6 +83,7 @@ struct pqd_handle {
 
   DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
+  DevBuf row_starts;
   int64_t bytes_len = 0;
   PinnedBuf stage_in, stage_meta, host_small;
 
@@ -94,6 +95,7 @@ struct pqd_handle {
   int elem_size = 0;
   bool busy = false;
   bool have_result = false;
+  bool levels_only = false;          // the last call decoded levels and counts only (skip path)
   pqd_chunk_result result{};
   ChunkCtx ctx{};
 
@@ -185,8 +187,9 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // The whole per-chunk sequence; d_in already holds the chunk bytes.
 int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_page_desc *pages, int32_t n_pages,
-                     const pqd_column_desc *col) {
+                     const pqd_column_desc *col, bool levels_only = false) {
   h->have_result = false;
+  h->levels_only = levels_only;
   h->n_events = 0;
   h->col = *col;
   h->n_pages = n_pages;
@@ -315,7 +318,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if ((rc = h->tile_desc.ensure(sizeof(TileDesc) * ((size_t)std::max(tp_levels.back(), tp_dict.back()) + 1)))) return rc;
   const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
   const bool nullable = col->max_def > 0;
-  if (!is_bytes) {
+  if (levels_only) {
+    // nothing but the level arrays
+  } else if (!is_bytes) {
     if ((rc = h->values.ensure(val_bytes))) return rc;
     if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
   } else {
@@ -409,7 +414,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
-  if (is_bytes) {
+  if (levels_only) {
+    // skip path (layout/page.go:433-559): levels, null and row counts; the value sections stay as they are
+  } else if (is_bytes) {
     // ---- BYTE_ARRAY: value descriptors (pairs) per encoding, offsets by a chunk-wide scan, then the copies ----
     ChunkCtx c8 = c;
     c8.elem_size = 8;
@@ -605,7 +612,7 @@ int pqd_handle_destroy(pqd_handle *h) {
   if (h->ev_done) (void)hipEventDestroy(h->ev_done);
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
                     &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
-                    &h->doff, &h->dict_pairs, &h->tile_desc};
+                    &h->doff, &h->dict_pairs, &h->tile_desc, &h->row_starts};
   for (DevBuf *b : bufs) b->release();
   h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -641,6 +648,27 @@ int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_
   return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col);
 }
 
+int pqd_decode_levels_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
+                             const pqd_column_desc *col) {
+  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !d_chunk)) return fail_arg("NULL argument");
+  Guard g(h->device);
+  return decode_on_device(h, static_cast<const uint8_t *>(d_chunk), len, pages, n_pages, col, true);
+}
+
+int pqd_decode_levels(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
+                      const pqd_column_desc *col) {
+  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !chunk)) return fail_arg("NULL argument");
+  Guard g(h->device);
+  int rc;
+  const size_t padded = align_up(len + 64, 256);
+  if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(h->stage_in.p, chunk, len);
+  std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
+  HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
+  return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col, true);
+}
+
 int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
   if (!h) return fail_arg("handle is NULL");
   Guard g(h->device);
@@ -668,13 +696,13 @@ int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
 int pqd_result_device(pqd_handle *h, pqd_device_result *out) {
   if (!h || !out) return fail_arg("NULL argument");
   if (!h->have_result) return fail_arg("no completed decode call");
-  out->values = h->values.p;
+  out->values = h->levels_only ? nullptr : h->values.p;
   out->def_levels = h->col.max_def > 0 ? static_cast<int32_t *>(h->def.p) : nullptr;
   out->rep_levels = h->col.max_rep > 0 ? static_cast<int32_t *>(h->rep.p) : nullptr;
   const bool is_bytes = h->col.physical_type == PQD_BYTE_ARRAY;
   if (is_bytes) out->values = nullptr;
-  out->offsets = is_bytes ? static_cast<int64_t *>(h->offsets.p) : nullptr;
-  out->bytes = is_bytes ? static_cast<uint8_t *>(h->bytes.p) : nullptr;
+  out->offsets = is_bytes && !h->levels_only ? static_cast<int64_t *>(h->offsets.p) : nullptr;
+  out->bytes = is_bytes && !h->levels_only ? static_cast<uint8_t *>(h->bytes.p) : nullptr;
   return PQD_OK;
 }
 
@@ -684,6 +712,7 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
   Guard g(h->device);
   const size_t n = (size_t)h->total_slots;
   const bool is_bytes = h->col.physical_type == PQD_BYTE_ARRAY;
+  if (h->levels_only && (values || offsets || bytes)) return fail_arg("the last call decoded levels only");
   if (values && n && !is_bytes) HIP_TRY(hipMemcpyAsync(values, h->values.p, n * (size_t)h->elem_size, hipMemcpyDeviceToHost, h->stream));
   if (is_bytes && h->result.status == PQD_OK) {
     if (offsets) HIP_TRY(hipMemcpyAsync(offsets, h->offsets.p, 8 * (n + 1), hipMemcpyDeviceToHost, h->stream));
@@ -698,6 +727,25 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
     else std::memset(rep_levels, 0, 4 * n);
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
+int pqd_row_starts(pqd_handle *h, int64_t *host_out, int64_t cap, int64_t **device_out) {
+  if (!h) return fail_arg("handle is NULL");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  if (h->result.status != PQD_OK) return fail_arg("the last decode call failed");
+  Guard g(h->device);
+  const int64_t n_rows = h->result.num_rows, n_slots = h->total_slots;
+  if (host_out && cap < n_rows + 1) return fail_arg("row_starts needs num_rows + 1 entries");
+  int rc;
+  if ((rc = h->row_starts.ensure(8 * (size_t)(n_rows + 2) + 64))) return rc;
+  if ((rc = h->scratch.ensure(8 * ((size_t)n_slots / 4096 + 8) + 64))) return rc;
+  int64_t *d = static_cast<int64_t *>(h->row_starts.p);
+  HIP_TRY(launch_row_starts(h->col.max_rep > 0 ? static_cast<const int32_t *>(h->rep.p) : nullptr, n_slots, n_rows,
+                            static_cast<int64_t *>(h->scratch.p), d, h->stream));
+  if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d, 8 * (size_t)(n_rows + 1), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (device_out) *device_out = d;
   return PQD_OK;
 }
 

@@ -34,6 +34,9 @@ hipError_t launch_plain_boolean(const ChunkCtx &c, const int32_t *tile_prefix, i
                                 hipStream_t stream);
 hipError_t launch_scatter_rank(const int32_t *def_levels, int64_t n_slots, int max_def, int64_t *partial, int n_tiles,
                                hipStream_t stream);
+// slot index of every row start (repetition level 0) + end marker; rep_levels NULL: a flat column
+hipError_t launch_row_starts(const int32_t *rep_levels, int64_t n_slots, int64_t n_rows, int64_t *scratch, int64_t *out,
+                             hipStream_t stream);
 hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, const uint8_t *dense, uint8_t *out,
                                 int64_t n_slots, int64_t *scratch, hipStream_t stream);
 

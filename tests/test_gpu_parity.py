@@ -244,6 +244,92 @@ def test_byte_stream_split(dec, oracle, ptype, dt):
     assert o.status == oracle.UNSUPPORTED
 
 
+@pytest.mark.parametrize("ptype", [pg.INT64, pg.BYTE_ARRAY])
+def test_levels_only_skip_path(dec, oracle, ptype):
+    # what SkipRows needs (layout/page.go:433-559): levels, nulls and rows per page, values untouched
+    rng = np.random.default_rng(77 + ptype)
+    cb = pg.ChunkBuilder(gap=4)
+    for n, v2 in ((1, False), (3000, True), (70000, False), (9, True)):
+        dl, rl = _levels(rng, n, 3, 1)
+        nn = int((dl == 3).sum())
+        if ptype == pg.INT64:
+            body = rng.integers(-2**62, 2**62, nn, dtype=np.int64).tobytes()
+        else:
+            body = pg.plain_byte_array([b"x" * int(k) for k in rng.integers(0, 9, nn)])
+        if v2:
+            cb.data_page_v2(pg.ENC_PLAIN, n, body, pg.hybrid_encode(rl, 1, rng), pg.hybrid_encode(dl, 2, rng))
+        else:
+            cb.data_page_v1(pg.ENC_PLAIN, n, body, pg.level_block_v1(rl, 1, rng), pg.level_block_v1(dl, 3, rng, "arrow"))
+    chunk, pages = cb.finish()
+    o = oracle.read_chunk(chunk, pages, ptype, 0, 3, 1)
+    g = dec.decode_levels(chunk, pages, ptype, 0, 3, 1)
+    assert g.status == o.status == 0 and g.kind == "levels"
+    assert (g.n_slots, g.n_rows, g.n_nulls) == (o.n_slots, o.n_rows, o.n_nulls)
+    assert np.array_equal(g.def_levels, o.def_levels) and np.array_equal(g.rep_levels, o.rep_levels)
+    # the handle still decodes values afterwards
+    check_same(dec, oracle, chunk, pages, ptype, 0, 3, 1)
+    # a broken level section is reported the same way
+    cb.data_page_v1(pg.ENC_PLAIN, 10, b"", b"\x02\x00\x00\x00\x03\x00", b"\x05\x00")
+    chunk, pages = cb.finish()
+    o = oracle.read_chunk(chunk, pages, ptype, 0, 3, 1)
+    g = dec.decode_levels(chunk, pages, ptype, 0, 3, 1)
+    assert g.status == o.status != 0 and g.bad_page == o.bad_page
+
+
+@pytest.mark.parametrize("ptype,max_rep", [(pg.INT64, 1), (pg.BYTE_ARRAY, 2), (pg.INT32, 0)])
+def test_column_buffer_read_rows(dec, oracle, ptype, max_rep):
+    # ReadRows / Table.Pop over several chunks (reader/columnbuffer.go:232-262, layout/table.go:73-103): rows that
+    # continue across a chunk boundary, requests larger than what is left, requests of zero rows
+    import parquet_go_amd as pq
+    rng = np.random.default_rng(300 + ptype + max_rep)
+    max_def = 2
+    chunks, tables = [], []
+    for c in range(3):
+        cb = pg.ChunkBuilder(gap=1)
+        for n in (1500, 1, 8000):
+            dl, rl = _levels(rng, n, max_def, max_rep)
+            if max_rep:
+                rl[rng.random(n) < 0.7] = rng.integers(1, max_rep + 1)   # long rows
+                if c == 0:
+                    rl[0] = 0
+                # (chunks after the first may start in the middle of a row)
+            nn = int((dl == max_def).sum())
+            if ptype == pg.BYTE_ARRAY:
+                body = pg.plain_byte_array([b"v%d" % k for k in rng.integers(0, 1000, nn)])
+            else:
+                body = rng.integers(0, 2**31 - 1, nn).astype(np.int64 if ptype == pg.INT64 else np.int32).tobytes()
+            cb.data_page_v1(pg.ENC_PLAIN, n, body, pg.level_block_v1(rl, max_rep, rng) if max_rep else b"",
+                            pg.level_block_v1(dl, max_def, rng))
+        chunk, pages = cb.finish()
+        chunks.append((chunk, pages))
+        tables.append(oracle.read_chunk(chunk, pages, ptype, 0, max_def, max_rep))
+    model = oracle.ColumnBufferModel(tables)
+    whole_def = np.concatenate([t.def_levels for t in tables])
+    whole_rep = np.concatenate([t.rep_levels for t in tables])
+    cbuf = pq.ColumnBuffer(dec, chunks, ptype, 0, max_def, max_rep)
+    pos = 0
+    for num in [0, 1, 7, 300, 2, 5000, 1, 10**9, 5]:
+        want_slots, want_rows = model.read_rows(num)
+        got, rows = cbuf.read_rows(num)
+        assert rows == want_rows, num
+        assert got.def_levels.size == want_slots, num
+        assert np.array_equal(got.def_levels, whole_def[pos:pos + want_slots])
+        assert np.array_equal(got.rep_levels, whole_rep[pos:pos + want_slots])
+        # values of the slice against the whole-table decode
+        if ptype == pg.BYTE_ARRAY:
+            lens = np.diff(got.offsets)
+            ref_lens = np.concatenate([np.diff(t.offsets) for t in tables])[pos:pos + want_slots]
+            assert np.array_equal(lens, ref_lens)
+            ref_bytes = np.concatenate([t.bytes for t in tables])
+            ref_off = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(t.offsets) for t in tables]))])
+            assert np.array_equal(got.bytes, ref_bytes[ref_off[pos]:ref_off[pos + want_slots]])
+        else:
+            ref_vals = np.concatenate([t.values for t in tables])
+            assert np.array_equal(got.values, ref_vals[pos:pos + want_slots])
+        pos += want_slots
+    assert pos == whole_def.size
+
+
 def test_empty_and_all_null(dec, oracle):
     cb = pg.ChunkBuilder()
     chunk, pages = cb.finish()
