@@ -124,6 +124,39 @@ int pqd_set_profiling(pqd_handle *h, int on);
 int pqd_scan_pages(const uint8_t *chunk, size_t len, int64_t total_values, pqd_page_desc *out, int32_t cap,
                    int32_t *n_out);
 
+/* ---- footer walk (host) ----
+ * pqd_footer_locate: the last 8 bytes of a file -> length of the thrift FileMetaData in front of them (checks the
+ * PAR1 magic; ParquetReader.GetFooterSize, reader/reader.go:148-160).
+ * pqd_footer_parse: the FileMetaData bytes -> leaf columns (physical type, type length, maximum definition and
+ * repetition level as schema.SchemaHandler derives them, schema/schemahandler.go:101-135, dotted path without the
+ * root) and one entry per column chunk (row group, leaf, codec, file offset of its first page as
+ * ColumnBufferType.NextRowGroup picks it, reader/columnbuffer.go:89-99, byte length, values, rows).
+ * Replaces ParquetReader.ReadFooter (reader/reader.go:162-176) for what the decode path needs. */
+typedef struct {
+  int32_t physical_type, type_length, max_def, max_rep;
+  int32_t schema_index;   /* position in the flattened schema list */
+  char path[236];         /* "a.b.c", NUL terminated, truncated if longer */
+} pqd_leaf_desc;
+typedef struct {
+  int32_t row_group, leaf;
+  int32_t codec;          /* parquet.CompressionCodec; only UNCOMPRESSED (0) chunks can be decoded */
+  int32_t reserved;
+  int64_t offset;         /* file offset of the chunk's first page header */
+  int64_t total_compressed_size;
+  int64_t num_values;     /* level slots in the chunk */
+  int64_t num_rows;       /* rows of the row group */
+} pqd_chunk_desc;
+typedef struct pqd_footer pqd_footer;
+int pqd_footer_locate(const uint8_t *tail8, size_t len, int64_t *footer_len);
+int pqd_footer_parse(const uint8_t *footer, size_t len, pqd_footer **out);
+void pqd_footer_free(pqd_footer *f);
+int64_t pqd_footer_num_rows(const pqd_footer *f);
+int32_t pqd_footer_num_row_groups(const pqd_footer *f);
+int32_t pqd_footer_num_leaves(const pqd_footer *f);
+int32_t pqd_footer_num_chunks(const pqd_footer *f);
+int pqd_footer_leaf(const pqd_footer *f, int32_t i, pqd_leaf_desc *out);
+int pqd_footer_chunk(const pqd_footer *f, int32_t i, pqd_chunk_desc *out);
+
 /* Decode one column chunk whose bytes are in HOST memory: copies them through pinned staging to the
  * device, then runs the same kernels as pqd_decode_chunk_device.  Asynchronous on the handle's stream
  * apart from the staging copy; pqd_wait() completes it.

@@ -5,7 +5,7 @@ package only loads the library for tests and benchmarks.  There is no CPU fallba
 an ImportError at first use.
 """
 from .binding import (  # noqa: F401
-    PAGE_DESC_DTYPE, Decoder, DecodeError, Table, lib, lib_path, scan_pages, strerror,
+    PAGE_DESC_DTYPE, Decoder, DecodeError, Table, lib, lib_path, read_footer, scan_pages, strerror,
     BOOLEAN, INT32, INT64, INT96, FLOAT, DOUBLE, BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY,
     ENC_PLAIN, ENC_PLAIN_DICTIONARY, ENC_RLE, ENC_BIT_PACKED, ENC_DELTA_BINARY_PACKED,
     ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY, ENC_RLE_DICTIONARY, ENC_BYTE_STREAM_SPLIT,

@@ -30,6 +30,16 @@ class _ColDesc(C.Structure):
     _fields_ = [("physical_type", C.c_int32), ("type_length", C.c_int32), ("max_def", C.c_int32), ("max_rep", C.c_int32)]
 
 
+class _LeafDesc(C.Structure):
+    _fields_ = [("physical_type", C.c_int32), ("type_length", C.c_int32), ("max_def", C.c_int32), ("max_rep", C.c_int32),
+                ("schema_index", C.c_int32), ("path", C.c_char * 236)]
+
+
+class _ChunkDesc(C.Structure):
+    _fields_ = [("row_group", C.c_int32), ("leaf", C.c_int32), ("codec", C.c_int32), ("reserved", C.c_int32),
+                ("offset", C.c_int64), ("total_compressed_size", C.c_int64), ("num_values", C.c_int64), ("num_rows", C.c_int64)]
+
+
 class _ChunkResult(C.Structure):
     _fields_ = [("num_slots", C.c_int64), ("num_values", C.c_int64), ("num_nulls", C.c_int64), ("num_rows", C.c_int64),
                 ("bytes_len", C.c_int64), ("elem_size", C.c_int32), ("status", C.c_int32), ("bad_page", C.c_int32),
@@ -78,6 +88,15 @@ def lib():
         L.pqd_decode_chunk_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_levels_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
+        L.pqd_footer_locate.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
+        L.pqd_footer_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.pqd_footer_free.argtypes = [C.c_void_p]
+        L.pqd_footer_free.restype = None
+        for fn in (L.pqd_footer_num_row_groups, L.pqd_footer_num_leaves, L.pqd_footer_num_chunks):
+            fn.argtypes, fn.restype = [C.c_void_p], C.c_int32
+        L.pqd_footer_num_rows.argtypes, L.pqd_footer_num_rows.restype = [C.c_void_p], C.c_int64
+        L.pqd_footer_leaf.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_LeafDesc)]
+        L.pqd_footer_chunk.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_ChunkDesc)]
         L.pqd_row_starts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.pqd_wait.argtypes = [C.c_void_p, C.POINTER(_ChunkResult)]
         L.pqd_result_device.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
@@ -108,6 +127,37 @@ def scan_pages(chunk, total_values=-1, cap=None):
     if rc != 0:
         raise DecodeError(rc, page=n.value)
     return out[:n.value].copy()
+
+
+def read_footer(file_bytes):
+    """Footer of a whole Parquet file held in memory -> dict(num_rows, num_row_groups, leaves=[...], chunks=[...]).
+    Host code only (no GPU needed)."""
+    a = np.frombuffer(file_bytes, dtype=np.uint8)
+    if a.size < 12:
+        raise DecodeError(-12)
+    flen = C.c_int64(0)
+    tail = a[-8:].copy()
+    _check(lib().pqd_footer_locate(C.c_void_p(tail.ctypes.data), 8, C.byref(flen)))
+    if flen.value < 0 or flen.value + 8 > a.size:
+        raise DecodeError(-12)
+    foot = a[a.size - 8 - flen.value:a.size - 8].copy()
+    h = C.c_void_p()
+    _check(lib().pqd_footer_parse(C.c_void_p(foot.ctypes.data), foot.size, C.byref(h)))
+    try:
+        out = {"num_rows": lib().pqd_footer_num_rows(h), "num_row_groups": lib().pqd_footer_num_row_groups(h), "leaves": [], "chunks": []}
+        for i in range(lib().pqd_footer_num_leaves(h)):
+            d = _LeafDesc()
+            _check(lib().pqd_footer_leaf(h, i, C.byref(d)))
+            out["leaves"].append({"path": d.path.decode(), "physical_type": d.physical_type, "type_length": d.type_length,
+                                  "max_def": d.max_def, "max_rep": d.max_rep})
+        for i in range(lib().pqd_footer_num_chunks(h)):
+            d = _ChunkDesc()
+            _check(lib().pqd_footer_chunk(h, i, C.byref(d)))
+            out["chunks"].append({k: getattr(d, k) for k in ("row_group", "leaf", "codec", "offset", "total_compressed_size",
+                                                             "num_values", "num_rows")})
+    finally:
+        lib().pqd_footer_free(h)
+    return out
 
 
 class Table:

@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t dpp_shr(uint32_t x, int n) {
 }
 // lane `sel` of `old` replaced by the wave-uniform value `val`
 __device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t val, int sel) {
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(sel) : "m0");
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(sel));  // (m0 is not otherwise used in this kernel)
   return old;
 }
 // inclusive prefix sum over the 64 lanes

@@ -140,6 +140,61 @@ def test_oracle_matches_pyarrow(parquet_file, oracle):
     assert {0, 5, 6, 7, 9}.issubset(seen_enc) and (2 in seen_enc or 8 in seen_enc)
 
 
+def test_footer_walk_matches_pyarrow(parquet_file):
+    """The C++ footer walk against pyarrow's view of the same footer: leaves, levels, chunk offsets and counts."""
+    import parquet_go_amd as pq
+    raw = open(parquet_file, "rb").read()
+    foot = pq.read_footer(raw)
+    f = pq_.ParquetFile(parquet_file)
+    md = f.metadata
+    assert foot["num_rows"] == md.num_rows and foot["num_row_groups"] == md.num_row_groups
+    assert len(foot["leaves"]) == md.num_columns
+    for ci, leaf in enumerate(foot["leaves"]):
+        sc = f.schema.column(ci)
+        assert leaf["path"] == sc.path
+        assert leaf["physical_type"] == PHYS[sc.physical_type]
+        assert (leaf["max_def"], leaf["max_rep"]) == (sc.max_definition_level, sc.max_repetition_level)
+        assert leaf["type_length"] == (sc.length if sc.physical_type == "FIXED_LEN_BYTE_ARRAY" else leaf["type_length"])
+    assert len(foot["chunks"]) == md.num_row_groups * md.num_columns
+    k = 0
+    for rg in range(md.num_row_groups):
+        for ci in range(md.num_columns):
+            cm = md.row_group(rg).column(ci)
+            ch = foot["chunks"][k]
+            k += 1
+            start = cm.dictionary_page_offset if cm.has_dictionary_page and cm.dictionary_page_offset else cm.data_page_offset
+            assert (ch["row_group"], ch["leaf"], ch["codec"]) == (rg, ci, 0)
+            assert (ch["offset"], ch["total_compressed_size"], ch["num_values"]) == (start, cm.total_compressed_size, cm.num_values)
+            assert ch["num_rows"] == md.row_group(rg).num_rows
+
+
+def test_footer_walk_rejects_garbage():
+    import parquet_go_amd as pq
+    with pytest.raises(pq.DecodeError):
+        pq.read_footer(b"PAR1" + b"\x00" * 20 + b"\x05\x00\x00\x00NOPE")
+    with pytest.raises(pq.DecodeError):
+        pq.read_footer(b"PAR1" + b"\xff" * 40 + b"\x28\x00\x00\x00PAR1")
+
+
+@pytest.mark.gpu
+def test_gpu_reads_whole_file_through_the_footer(parquet_file, oracle):
+    """End to end on the library's own host code: footer walk -> chunk bytes -> page walk -> GPU decode."""
+    import parquet_go_amd as pq
+    raw = open(parquet_file, "rb").read()
+    foot = pq.read_footer(raw)
+    f = pq_.ParquetFile(parquet_file)
+    dec = pq.Decoder(0)
+    names = {v: k for k, v in PHYS.items()}
+    for ch in foot["chunks"]:
+        leaf = foot["leaves"][ch["leaf"]]
+        chunk = raw[ch["offset"]:ch["offset"] + ch["total_compressed_size"]]
+        pages = pq.scan_pages(chunk, ch["num_values"])
+        g = dec.decode(chunk, pages, leaf["physical_type"], leaf["type_length"], leaf["max_def"], leaf["max_rep"])
+        check_table(g, f, ch["row_group"], leaf["path"], names[leaf["physical_type"]], leaf["max_def"], ch["num_values"])
+        assert g.n_rows == ch["num_rows"]
+    dec.close()
+
+
 @pytest.mark.gpu
 def test_gpu_matches_pyarrow_and_oracle(parquet_file, oracle):
     import parquet_go_amd as pq
