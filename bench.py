@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the DELTA_BINARY_PACKED / host-to-host extras")
     ap.add_argument("--delta-values", type=int, default=512 << 20)
+    ap.add_argument("--list-slots", type=int, default=128 << 20)
+    ap.add_argument("--string-values", type=int, default=100_000_000)
     ap.add_argument("--iso-reps", type=int, default=3, help="serial launches per width for the isolated kernel durations")
     return ap.parse_args()
 
@@ -305,6 +307,67 @@ def run_extras(args, dec, local_rank):
         del dev
     except Exception as e:  # the extras never take the headline down
         extra["delta_int64"] = {"error": repr(e)}
+    def timed_device(chunk, pages, ptype, max_def=0, max_rep=0, reps=3):
+        dev = to_device(chunk)
+        torch.cuda.synchronize()
+        best, kt = None, {}
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            dec.submit_device(dev.data_ptr(), chunk.size, pages, ptype, 0, max_def, max_rep)
+            r = dec.wait()
+            dt = time.perf_counter() - t0
+            assert r.status == 0, r.status
+            if i and (best is None or dt < best):
+                best, kt = dt, dec.kernel_times()
+        return best, kt, r
+
+    # configs[4]: nested levels (optional list of optional int64), PLAIN values
+    try:
+        n = args.list_slots
+        chunk, pages = pqgen.list_chunk(0x5EED0005, n, 128 << 10)
+        in_bytes = int(pages["length"].sum())
+        best, kt, r = timed_device(chunk, pages, pq.INT64, 3, 1)
+        from oracle import oracle as orc
+        k = min(4, len(pages))
+        o = orc.read_chunk(chunk, pages[:k], orc.INT64, 0, 3, 1)
+        dec._is_bytes = False
+        g = dec.fetch(r)
+        ok = (np.array_equal(g.def_levels[:o.n_slots], o.def_levels) and np.array_equal(g.rep_levels[:o.n_slots], o.rep_levels)
+              and np.array_equal(g.values[:o.n_slots], o.values))
+        out_bytes = n * (4 + 4 + 8)
+        lv_ms = kt.get("k_hybrid_expand<levels>", (0.0, 1))[0]
+        extra["list_int64"] = {"workload": "configs[4]: optional list<optional int64>, %d Mi level slots (max_def 3, max_rep 1), pages of "
+                                           "128 Ki slots, PLAIN values; output = rep + def (int32 each) + slot-aligned int64 values"
+                                           % (n >> 20),
+                               "decoded_GBps": round(out_bytes / best / 1e9, 1), "ms": round(best * 1e3, 3),
+                               "rows": int(r.num_rows), "nulls": int(r.num_nulls),
+                               "kernel_ms": {k_: round(v[0], 3) for k_, v in kt.items()},
+                               "levels_expand_alg_GBps": round((n * 3 / 8 + n * 8) / lv_ms / 1e6, 1) if lv_ms else None,
+                               "sample_matches_oracle": bool(ok)}
+        del g
+    except Exception as e:
+        extra["list_int64"] = {"error": repr(e)}
+
+    # configs[3]: key-like strings, DELTA_LENGTH_BYTE_ARRAY and DELTA_BYTE_ARRAY
+    for mode, name in ((0, "delta_length_byte_array"), (1, "delta_byte_array")):
+        try:
+            n = args.string_values
+            chunk, pages = pqgen.strings_chunk(0x5EED0004, n, 64 << 10, mode)
+            in_bytes = int(pages["length"].sum())
+            dec._is_bytes = True
+            best, kt, r = timed_device(chunk, pages, pq.BYTE_ARRAY)
+            out_bytes = int(r.bytes_len) + 8 * (n + 1)
+            extra[name] = {"workload": "configs[3]: %d M strings of 8-64 bytes sharing prefixes with their predecessor, pages of 64 Ki "
+                                       "strings; output = int64 offsets + bytes" % (n // 1000000),
+                           "decoded_GBps": round(out_bytes / best / 1e9, 1), "ms": round(best * 1e3, 3),
+                           "in_bytes": in_bytes, "out_bytes": out_bytes,
+                           "alg_GBps": round((in_bytes + out_bytes) / best / 1e9, 1),
+                           "roofline_frac": round((in_bytes + out_bytes) / best / 1e9 / HBM_PEAK_GBPS, 4),
+                           "kernel_ms": {k_: round(v[0], 3) for k_, v in kt.items()}}
+        except Exception as e:
+            extra[name] = {"error": repr(e)}
+    dec._is_bytes = False
+
     try:
         n = 64 << 20
         chunk, pages = pqgen.dict_chunk(0x5EED0009, n, 12, 4096, 1 << 20)

@@ -249,12 +249,114 @@ __global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint6
 // visits exactly the candidates in order of decreasing prefix length.  The parents are found by pointer
 // jumping: cand[i] starts at i-1 and jumps to cand[cand[i]] while p[cand[i]] >= p[i].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_dba_parents(ChunkCtx c, int64_t *prefix, int32_t *parent) {
+constexpr int kChainMax = 1024;  // longest string the in-order chain kernel keeps in LDS
+
+// Per page: the first prefix length is ignored (encodingread.go:427), prefix lengths are range checked, and pages
+// holding a string longer than kChainMax are marked for the parent-chain kernels (flag 1); the others go through
+// k_dba_chain (flag 0).
+__global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix, const uint64_t *pairs, int32_t *page_flag) {
+  __shared__ int s_bad, s_long;
+  const int d = blockIdx.x, tid = threadIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (tid == 0) page_flag[d] = 0;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  const int cnt = ps->cnt;
+  if (tid == 0) { prefix[base] = 0; s_bad = 0; s_long = 0; }
+  __syncthreads();
+  int bad = 0, lng = 0;
+  for (int i = tid; i < cnt; i += 256) {
+    const int64_t pi = prefix[base + i];
+    if (pi < 0 || pi > kMaxStrLen) bad = 1;
+    else if (pi + (int64_t)(pairs[base + i] >> 40) > kChainMax) lng = 1;
+  }
+  if (bad) s_bad = 1;
+  if (lng) s_long = 1;
+  __syncthreads();
+  if (tid == 0) {
+    if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
+    else page_flag[d] = s_long;
+  }
+}
+
+// Pages without long strings, one wavefront per page, strings in order: lane j carries byte j of the previous
+// string; byte j of the next one is that byte when j lies in the shared prefix, else a byte of the suffix, loaded
+// eight strings ahead of its use.  Suffixes follow each other in the page and so do the outputs, so only the two
+// lengths are per-string inputs.  Strings of 65 .. kChainMax bytes keep the previous string in LDS instead.
+__global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int64_t *doff,
+                                                  const int32_t *page_flag, uint8_t *bytes_out) {
+  __shared__ uint8_t s_cur[kChainMax + 64];
+  const int d = blockIdx.x, lane = threadIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] != 0) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  const int cnt = ps->cnt;
+  uint32_t cur = 0;   // byte `lane` of the previous string
+  int len_prev = 0;
+  for (int i0 = 0; i0 < cnt; i0 += 64) {
+    const int nb = cnt - i0 < 64 ? cnt - i0 : 64;
+    int P = 0, S = 0;
+    if (lane < nb) { P = (int)prefix[base + i0 + lane]; S = (int)(pairs[base + i0 + lane] >> 40); }
+    int mx = P + S;
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    const uint8_t *src = c.in + (pairs[base + i0] & kSrcMask);  // suffix bytes of the batch, back to back
+    uint8_t *out = bytes_out + doff[base + i0];
+    if (mx <= 64) {
+      for (int k0 = 0; k0 < nb; k0 += 8) {
+        uint32_t ld[8];
+        const uint8_t *sp = src;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int k = k0 + u < nb ? k0 + u : nb - 1;
+          const int pk = __builtin_amdgcn_readlane(P, k), sk = k0 + u < nb ? __builtin_amdgcn_readlane(S, k) : 0;
+          ld[u] = 0;
+          if (lane >= pk && lane < pk + sk) ld[u] = sp[lane - pk];
+          sp += sk;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (k0 + u >= nb) break;
+          const int pk = __builtin_amdgcn_readlane(P, k0 + u), sk = __builtin_amdgcn_readlane(S, k0 + u);
+          if (pk > len_prev) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }  // slice beyond the previous string
+          const uint32_t b = lane < pk ? cur : ld[u];
+          if (lane < pk + sk) { out[lane] = (uint8_t)b; cur = b; }
+          out += pk + sk;
+          len_prev = pk + sk;
+        }
+        src = sp;
+      }
+    } else {
+      s_cur[lane] = (uint8_t)cur;
+      for (int k = 0; k < nb; k++) {
+        const int pk = __builtin_amdgcn_readlane(P, k), sk = __builtin_amdgcn_readlane(S, k);
+        if (pk > len_prev) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
+        const int len = pk + sk;
+        for (int j = lane; j < len; j += 64) {
+          uint8_t b;
+          if (j >= pk) { b = src[j - pk]; s_cur[j] = b; }
+          else b = s_cur[j];
+          out[j] = b;
+        }
+        __builtin_amdgcn_wave_barrier();
+        src += sk;
+        out += len;
+        len_prev = len;
+      }
+      cur = s_cur[lane];
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_dba_parents(ChunkCtx c, int64_t *prefix, int32_t *parent, const int32_t *page_flag) {
   __shared__ int s_changed;
   __shared__ int s_bad;
   const int d = blockIdx.x, tid = threadIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
-  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] == 0) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t base = ps->dense_base;
@@ -294,10 +396,10 @@ __global__ __launch_bounds__(1024) void k_dba_parents(ChunkCtx c, int64_t *prefi
 
 // one thread per string: suffix bytes straight, prefix bytes through the parent chain
 __global__ __launch_bounds__(256) void k_dba_resolve(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int32_t *parent,
-                                                     const int64_t *doff, uint8_t *bytes_out) {
+                                                     const int64_t *doff, const int32_t *page_flag, uint8_t *bytes_out) {
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
-  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] == 0) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t base = ps->dense_base;
@@ -397,11 +499,18 @@ hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, cons
   return hipGetLastError();
 }
 
+// phase 0: before the offsets exist (prefix checks, page classes, parent links of the pages with long strings);
+// phase 1: the copies
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
-                              uint8_t *bytes_out, int phase, hipStream_t stream) {
+                              int32_t *page_flag, uint8_t *bytes_out, int phase, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  if (phase == 0) hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent);
-  else hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, bytes_out);
+  if (phase == 0) {
+    hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag);
+    hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent, page_flag);
+  } else {
+    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out);
+    hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out);
+  }
   return hipGetLastError();
 }
 

@@ -202,9 +202,14 @@ __global__ __launch_bounds__(256) void k_scatter_count(const int32_t *def, int64
   __shared__ int s_cnt[4];
   const int64_t base = (int64_t)blockIdx.x * kScatterTile;
   int c = 0;
-  for (int i = threadIdx.x; i < kScatterTile; i += 256) {
-    int64_t s = base + i;
-    if (s < n) c += def[s] == max_def;
+  for (int i = threadIdx.x * 4; i < kScatterTile; i += 1024) {
+    const int64_t s = base + i;
+    if (s + 4 <= n) {
+      const int4 d = *reinterpret_cast<const int4 *>(def + s);
+      c += (d.x == max_def) + (d.y == max_def) + (d.z == max_def) + (d.w == max_def);
+    } else {
+      for (int j = 0; j < 4; j++) if (s + j < n) c += def[s + j] == max_def;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
@@ -236,40 +241,74 @@ __global__ __launch_bounds__(1024) void k_scatter_scan(int64_t *partial, int n_t
   }
 }
 
+// A block takes kScatterTile slots in four rounds of 1024: every thread reads four consecutive definition levels
+// with one 16-byte load (a wave covers 1 KiB of levels), the block scans the counts of valid slots, and the thread
+// writes its four slots with one or two 16-byte stores, taking its values from consecutive dense positions.
 template <int ESZ>
 __global__ __launch_bounds__(256) void k_scatter_apply(const int32_t *def, int64_t n, int max_def, const int64_t *partial,
                                                        const uint8_t *dense, uint8_t *out, int esz) {
   __shared__ int s_wave[4];
-  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // thread handles 16 consecutive slots
-  const int64_t s0 = base + (int64_t)tid * 16;
-  uint32_t valid = 0;
-  for (int j = 0; j < 16; j++)
-    if (s0 + j < n && def[s0 + j] == max_def) valid |= 1u << j;
-  int c = __builtin_popcount(valid);
-  int incl = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    int y = __shfl_up(incl, o);
-    if (lane >= o) incl += y;
-  }
-  if (lane == 63) s_wave[wv] = incl;
-  __syncthreads();
-  int wbase = 0;
-  for (int q = 0; q < wv; q++) wbase += s_wave[q];
-  int64_t rank = partial[blockIdx.x] + wbase + incl - c;
-  for (int j = 0; j < 16; j++) {
-    const int64_t s = s0 + j;
-    if (s >= n) break;
-    const bool v = (valid >> j) & 1u;
-    if (ESZ == 4) {
-      reinterpret_cast<uint32_t *>(out)[s] = v ? reinterpret_cast<const uint32_t *>(dense)[rank] : 0u;
-    } else if (ESZ == 8) {
-      reinterpret_cast<uint64_t *>(out)[s] = v ? reinterpret_cast<const uint64_t *>(dense)[rank] : 0ull;
-    } else {
-      for (int b = 0; b < esz; b++) out[s * esz + b] = v ? dense[rank * esz + b] : (uint8_t)0;
+  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
+  int64_t rank0 = partial[blockIdx.x];  // dense position of the tile's first valid slot
+#pragma unroll 1
+  for (int it = 0; it < kScatterTile / 1024; it++) {
+    const int64_t s0 = base + it * 1024 + tid * 4;
+    int4 d = make_int4(-1, -1, -1, -1);
+    if (s0 + 4 <= n) d = *reinterpret_cast<const int4 *>(def + s0);
+    else {
+      if (s0 < n) d.x = def[s0];
+      if (s0 + 1 < n) d.y = def[s0 + 1];
+      if (s0 + 2 < n) d.z = def[s0 + 2];
     }
-    rank += v;
+    const bool v0 = s0 < n && d.x == max_def, v1 = s0 + 1 < n && d.y == max_def, v2 = s0 + 2 < n && d.z == max_def,
+               v3 = s0 + 3 < n && d.w == max_def;
+    const int c = (int)v0 + (int)v1 + (int)v2 + (int)v3;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    __syncthreads();  // the previous round's totals have been read
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { if (q < wv) wbase += s_wave[q]; total += s_wave[q]; }
+    int64_t r = rank0 + wbase + incl - c;
+    rank0 += total;
+    if (s0 >= n) continue;
+    if (ESZ == 4) {
+      const uint32_t *dn = reinterpret_cast<const uint32_t *>(dense);
+      uint32_t y[4];
+      y[0] = v0 ? dn[r] : 0u; r += v0;
+      y[1] = v1 ? dn[r] : 0u; r += v1;
+      y[2] = v2 ? dn[r] : 0u; r += v2;
+      y[3] = v3 ? dn[r] : 0u;
+      uint32_t *o = reinterpret_cast<uint32_t *>(out) + s0;
+      if (s0 + 4 <= n) { V16Unaligned x = {{y[0], y[1], y[2], y[3]}}; *reinterpret_cast<V16Unaligned *>(o) = x; }
+      else for (int j = 0; s0 + j < n; j++) o[j] = y[j];
+    } else if (ESZ == 8) {
+      const uint64_t *dn = reinterpret_cast<const uint64_t *>(dense);
+      uint64_t y[4];
+      y[0] = v0 ? dn[r] : 0ull; r += v0;
+      y[1] = v1 ? dn[r] : 0ull; r += v1;
+      y[2] = v2 ? dn[r] : 0ull; r += v2;
+      y[3] = v3 ? dn[r] : 0ull;
+      uint64_t *o = reinterpret_cast<uint64_t *>(out) + s0;
+      if (s0 + 4 <= n) {
+        V16Unaligned x0 = {{(uint32_t)y[0], (uint32_t)(y[0] >> 32), (uint32_t)y[1], (uint32_t)(y[1] >> 32)}};
+        V16Unaligned x1 = {{(uint32_t)y[2], (uint32_t)(y[2] >> 32), (uint32_t)y[3], (uint32_t)(y[3] >> 32)}};
+        reinterpret_cast<V16Unaligned *>(o)[0] = x0;
+        reinterpret_cast<V16Unaligned *>(o)[1] = x1;
+      } else for (int j = 0; s0 + j < n; j++) o[j] = y[j];
+    } else {
+      const bool vv[4] = {v0, v1, v2, v3};
+      for (int j = 0; j < 4 && s0 + j < n; j++) {
+        for (int b = 0; b < esz; b++) out[(s0 + j) * esz + b] = vv[j] ? dense[r * esz + b] : (uint8_t)0;
+        r += vv[j];
+      }
+    }
   }
 }
 

@@ -83,7 +83,7 @@ struct pqd_handle {
 
   DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
-  DevBuf row_starts;
+  DevBuf row_starts, dba_flags;
   int64_t bytes_len = 0;
   PinnedBuf stage_in, stage_meta, host_small;
 
@@ -327,6 +327,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     const size_t n8 = 8 * ((size_t)slots + 2) + 64;
     if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->offsets.ensure(n8))) return rc;
     if ((any_dlba || any_dba) && (rc = h->lens64.ensure(n8))) return rc;
+    if (any_dba && (rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
     if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
     if ((rc = h->scratch.ensure(8 * ((size_t)slots / 2048 + 8) + 64))) return rc;
   }
@@ -446,7 +447,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, h->stream)); }
       { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
-      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, nullptr, 0, h->stream)); }
+      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, h->stream)); }
     }
     for (int p = 0; p < n_pages && host_status == PQD_OK; p++) {
       const PageIn &pi = h->h_pages[(size_t)p];
@@ -473,7 +474,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     bool all_dlba = any_dlba && !any_dba && !any_plain && !any_dict_enc;
     if (any_plain || any_dict_enc || (any_dlba && !all_dlba)) { Prof pf(h, "k_copy_values"); HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, h->stream)); }
     if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, bytes_out, h->stream)); }
-    if (any_dba) { Prof pf(h, "k_dba_resolve"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, bytes_out, 1, h->stream)); }
+    if (any_dba) { Prof pf(h, "k_dba_resolve"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), bytes_out, 1, h->stream)); }
     if (nullable) {
       const int n_tiles = (int)((slots + 1 + 4095) / 4096);
       if ((rc = h->scratch.ensure(8 * (size_t)n_tiles + 64))) return rc;
@@ -612,7 +613,7 @@ int pqd_handle_destroy(pqd_handle *h) {
   if (h->ev_done) (void)hipEventDestroy(h->ev_done);
   DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
                     &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
-                    &h->doff, &h->dict_pairs, &h->tile_desc, &h->row_starts};
+                    &h->doff, &h->dict_pairs, &h->tile_desc, &h->row_starts, &h->dba_flags};
   for (DevBuf *b : bufs) b->release();
   h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);

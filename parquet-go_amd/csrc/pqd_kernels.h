@@ -56,6 +56,7 @@ hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const in
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
                                   hipStream_t stream);
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
+                              int32_t *page_flag,
                               uint8_t *bytes_out, int phase, hipStream_t stream);
 hipError_t launch_scatter_offsets(const int32_t *def, int64_t n_slots, int max_def, const int64_t *partial, const int64_t *doff,
                                   int64_t *slot_off, hipStream_t stream);

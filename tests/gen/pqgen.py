@@ -38,6 +38,14 @@ def lib():
         L.pqgen_delta_chunk.restype = C.c_int32
         L.pqgen_delta_chunk.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.pqgen_list_slot_bytes.restype = C.c_int64
+        L.pqgen_list_slot_bytes.argtypes = [C.c_int64]
+        L.pqgen_list_chunk.restype = C.c_int32
+        L.pqgen_list_chunk.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.pqgen_strings_slot_bytes.restype = C.c_int64
+        L.pqgen_strings_slot_bytes.argtypes = [C.c_int64]
+        L.pqgen_strings_chunk.restype = C.c_int32
+        L.pqgen_strings_chunk.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -66,3 +74,25 @@ def delta_chunk(seed, n_values, w, page_values, elem_size=8, start=1_700_000_000
                                 pages.ctypes.data, pages.size)
     assert n == n_pages, n
     return buf[:cap], pages
+
+
+def list_chunk(seed, n_slots, page_slots):
+    """-> (chunk, pages): optional list<optional int64> column chunk (max_def 3, max_rep 1), PLAIN INT64 values."""
+    n_pages = (n_slots + page_slots - 1) // page_slots
+    cap = n_pages * lib().pqgen_list_slot_bytes(page_slots) + 64
+    buf = np.zeros(cap, np.uint8)
+    pages = np.zeros(n_pages, PAGE_DESC_DTYPE)
+    n = lib().pqgen_list_chunk(seed, n_slots, page_slots, buf.ctypes.data, buf.size, pages.ctypes.data, pages.size)
+    assert n == n_pages, n
+    return buf, pages
+
+
+def strings_chunk(seed, n_values, page_values, mode):
+    """-> (chunk, pages): BYTE_ARRAY chunk of key-like strings.  mode 0 DELTA_LENGTH_BYTE_ARRAY, 1 DELTA_BYTE_ARRAY, 2 PLAIN."""
+    n_pages = (n_values + page_values - 1) // page_values
+    cap = n_pages * lib().pqgen_strings_slot_bytes(page_values) + 64
+    buf = np.zeros(cap, np.uint8)
+    pages = np.zeros(n_pages, PAGE_DESC_DTYPE)
+    n = lib().pqgen_strings_chunk(seed, n_values, page_values, mode, buf.ctypes.data, buf.size, pages.ctypes.data, pages.size)
+    assert n == n_pages, n
+    return buf, pages

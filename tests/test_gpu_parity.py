@@ -276,6 +276,36 @@ def test_levels_only_skip_path(dec, oracle, ptype):
     assert g.status == o.status != 0 and g.bad_page == o.bad_page
 
 
+def test_delta_byte_array_length_classes(dec, oracle):
+    # pages of short strings (one 64-byte row of lanes), of strings up to 1 KiB (previous string kept in LDS) and with
+    # longer ones (parent-chain kernels), batches that mix the first two, and a prefix that overruns its predecessor
+    rng = np.random.default_rng(4242)
+
+    def keys(n, lo, hi):
+        out, prev = [], b""
+        for _ in range(n):
+            ln = int(rng.integers(lo, hi + 1))
+            pl = int(rng.integers(0, min(len(prev), ln) + 1))
+            cur = prev[:pl] + bytes(rng.integers(97, 123, ln - pl, dtype=np.uint8))
+            out.append(cur)
+            prev = cur
+        return out
+
+    cb = pg.ChunkBuilder(gap=2)
+    for strings in (keys(3000, 0, 64), keys(1000, 0, 300), keys(700, 900, 1024), keys(300, 0, 64) + keys(200, 60, 70) + keys(300, 1, 9),
+                    keys(200, 0, 3000), keys(1, 5, 5), keys(65, 64, 64)):
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(strings), pg.dba_encode(strings))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == 0
+    # prefix longer than the previous string: the reference panics on the slice (encodingread.go:430)
+    bad = pg.delta_encode(np.array([0, 3, 9], np.int32), np.int32) + pg.dlba_encode([b"abc", b"de", b"f"])
+    cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, 3, bad)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == oracle.PANIC
+
+
 @pytest.mark.parametrize("ptype,max_rep", [(pg.INT64, 1), (pg.BYTE_ARRAY, 2), (pg.INT32, 0)])
 def test_column_buffer_read_rows(dec, oracle, ptype, max_rep):
     # ReadRows / Table.Pop over several chunks (reader/columnbuffer.go:232-262, layout/table.go:73-103): rows that
