@@ -282,9 +282,18 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 }
 
 // Pages without long strings, one wavefront per page, strings in order: lane j carries byte j of the previous
-// string; byte j of the next one is that byte when j lies in the shared prefix, else a byte of the suffix, loaded
-// eight strings ahead of its use.  Suffixes follow each other in the page and so do the outputs, so only the two
-// lengths are per-string inputs.  Strings of 65 .. kChainMax bytes keep the previous string in LDS instead.
+// string; byte j of the next one is that byte when j lies in the shared prefix, else a byte of the suffix.
+// Suffixes follow each other in the page and so do the outputs, so only the two lengths are per-string inputs.
+// The page is walked in batches of 64 strings: the suffix bytes of the next batch and the lengths of the one after
+// it are in flight while the current batch is chained together (one wave per page leaves nothing else to hide the
+// load latency behind).  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS.
+struct DbaBatch {
+  int P, S;            // this lane's string: prefix and suffix length
+  int mx;              // longest string of the batch
+  const uint8_t *src;  // suffix bytes of the batch, back to back
+  uint8_t *out;        // output of the batch's first string
+};
+
 __global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int64_t *doff,
                                                   const int32_t *page_flag, uint8_t *bytes_out) {
   __shared__ uint8_t s_cur[kChainMax + 64];
@@ -295,44 +304,76 @@ __global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *pre
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t base = ps->dense_base;
   const int cnt = ps->cnt;
-  uint32_t cur = 0;   // byte `lane` of the previous string
-  int len_prev = 0;
-  for (int i0 = 0; i0 < cnt; i0 += 64) {
-    const int nb = cnt - i0 < 64 ? cnt - i0 : 64;
-    int P = 0, S = 0;
-    if (lane < nb) { P = (int)prefix[base + i0 + lane]; S = (int)(pairs[base + i0 + lane] >> 40); }
+
+  auto fetch_lengths = [&](int i0, int &P, int &S, uint64_t &pr0, int64_t &o0) {
+    P = 0; S = 0; pr0 = 0; o0 = 0;
+    if (i0 < cnt) {
+      if (i0 + lane < cnt) { P = (int)prefix[base + i0 + lane]; S = (int)(pairs[base + i0 + lane] >> 40); }
+      pr0 = pairs[base + i0];
+      o0 = doff[base + i0];
+    }
+  };
+  auto make_batch = [&](int P, int S, uint64_t pr0, int64_t o0) {
+    DbaBatch b;
+    b.P = P; b.S = S;
     int mx = P + S;
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-    const uint8_t *src = c.in + (pairs[base + i0] & kSrcMask);  // suffix bytes of the batch, back to back
-    uint8_t *out = bytes_out + doff[base + i0];
-    if (mx <= 64) {
-      for (int k0 = 0; k0 < nb; k0 += 8) {
-        uint32_t ld[8];
-        const uint8_t *sp = src;
+    b.mx = mx;
+    b.src = c.in + (pr0 & kSrcMask);
+    b.out = bytes_out + o0;
+    return b;
+  };
+  // the suffix byte of every string of a batch that falls on this lane (strings of at most 64 bytes)
+  auto issue_loads = [&](const DbaBatch &b, int nb, uint32_t ld[64]) {
+    if (b.mx > 64) return;
+    const uint8_t *sp = b.src;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int k = k0 + u < nb ? k0 + u : nb - 1;
-          const int pk = __builtin_amdgcn_readlane(P, k), sk = k0 + u < nb ? __builtin_amdgcn_readlane(S, k) : 0;
-          ld[u] = 0;
-          if (lane >= pk && lane < pk + sk) ld[u] = sp[lane - pk];
-          sp += sk;
-        }
+    for (int u = 0; u < 64; u++) {
+      const int pk = __builtin_amdgcn_readlane(b.P, u), sk = __builtin_amdgcn_readlane(b.S, u);  // lanes beyond nb hold 0, 0
+      ld[u] = 0;
+      if (lane >= pk && lane < pk + sk) ld[u] = sp[lane - pk];
+      sp += sk;
+    }
+    (void)nb;
+  };
+
+  uint32_t cur = 0;   // byte `lane` of the previous string
+  int len_prev = 0;
+  uint32_t ld_a[64], ld_b[64];
+  int P1, S1, P2, S2;
+  uint64_t pr1, pr2;
+  int64_t o1, o2;
+  fetch_lengths(0, P1, S1, pr1, o1);
+  DbaBatch cb = make_batch(P1, S1, pr1, o1);
+  issue_loads(cb, cnt < 64 ? cnt : 64, ld_a);
+  fetch_lengths(64, P1, S1, pr1, o1);
+  for (int i0 = 0; i0 < cnt; i0 += 64) {
+    const int nb = cnt - i0 < 64 ? cnt - i0 : 64;
+    // next batch: its byte loads go out now; the lengths of the batch after it too
+    const DbaBatch nbatch = make_batch(P1, S1, pr1, o1);
+    const int nb_next = cnt - (i0 + 64) < 64 ? cnt - (i0 + 64) : 64;
+    if (i0 + 64 < cnt) issue_loads(nbatch, nb_next, ld_b);
+    fetch_lengths(i0 + 128, P2, S2, pr2, o2);
+
+    const uint8_t *src = cb.src;
+    uint8_t *out = cb.out;
+    if (cb.mx <= 64) {
+      bool bad = false;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          if (k0 + u >= nb) break;
-          const int pk = __builtin_amdgcn_readlane(P, k0 + u), sk = __builtin_amdgcn_readlane(S, k0 + u);
-          if (pk > len_prev) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }  // slice beyond the previous string
-          const uint32_t b = lane < pk ? cur : ld[u];
-          if (lane < pk + sk) { out[lane] = (uint8_t)b; cur = b; }
-          out += pk + sk;
-          len_prev = pk + sk;
-        }
-        src = sp;
+      for (int u = 0; u < 64; u++) {
+        // (lanes beyond the batch hold lengths 0, 0: nothing is written for them)
+        const int pk = __builtin_amdgcn_readlane(cb.P, u), sk = __builtin_amdgcn_readlane(cb.S, u);
+        bad = bad || (u < nb && pk > len_prev);  // slice beyond the previous string
+        const uint32_t b = lane < pk ? cur : ld_a[u];
+        if (!bad && lane < pk + sk) { out[lane] = (uint8_t)b; cur = b; }
+        out += pk + sk;
+        if (u < nb) len_prev = pk + sk;
       }
+      if (bad) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
     } else {
       s_cur[lane] = (uint8_t)cur;
       for (int k = 0; k < nb; k++) {
-        const int pk = __builtin_amdgcn_readlane(P, k), sk = __builtin_amdgcn_readlane(S, k);
+        const int pk = __builtin_amdgcn_readlane(cb.P, k), sk = __builtin_amdgcn_readlane(cb.S, k);
         if (pk > len_prev) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
         const int len = pk + sk;
         for (int j = lane; j < len; j += 64) {
@@ -348,6 +389,11 @@ __global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *pre
       }
       cur = s_cur[lane];
     }
+    // rotate
+    cb = nbatch;
+#pragma unroll
+    for (int u = 0; u < 64; u++) ld_a[u] = ld_b[u];
+    P1 = P2; S1 = S2; pr1 = pr2; o1 = o2;
   }
 }
 
