@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.err"; exit 1; }
 echo "kernel-trace pass done"
-SHORT="--no-cpu --no-extra --steps 1 --warmup 0 --iso-reps 1 --handles 1"
+SHORT="--no-cpu --no-extra --steps 1 --warmup 0 --iso-reps 1 --handles 1 --depth 1"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $SHORT > "$OUT/fetch.json" 2> "$OUT/fetch.err" || { echo "FETCH_SIZE pass failed"; tail -5 "$OUT/fetch.err"; exit 1; }
 echo "FETCH_SIZE pass done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" $SHORT > "$OUT/write.json" 2> "$OUT/write.err" || { echo "WRITE_SIZE pass failed"; tail -5 "$OUT/write.err"; exit 1; }
