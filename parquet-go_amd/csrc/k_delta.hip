@@ -212,65 +212,95 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
         seg_load(pf, base16, hi_seg, q_end, lane);
         __syncthreads();
       }
-      // 16 bytes at q, wave-uniform
+      // bytes at q, wave-uniform
       const uint32_t di = q >> 2, sh = (q & 3u) * 8u;
       uint32_t d0 = __builtin_amdgcn_readfirstlane(ring[di & (kRingDwords - 1)]);
       uint32_t d1 = __builtin_amdgcn_readfirstlane(ring[(di + 1) & (kRingDwords - 1)]);
       uint32_t d2 = __builtin_amdgcn_readfirstlane(ring[(di + 2) & (kRingDwords - 1)]);
-      uint32_t d3 = __builtin_amdgcn_readfirstlane(ring[(di + 3) & (kRingDwords - 1)]);
-      uint32_t d4 = __builtin_amdgcn_readfirstlane(ring[(di + 4) & (kRingDwords - 1)]);
       const uint64_t xlo = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
-      const uint64_t xhi = ((uint64_t)__builtin_amdgcn_alignbit(d4, d3, sh) << 32) | __builtin_amdgcn_alignbit(d3, d2, sh);
-      // minDelta varint (at most 10 bytes; a longer one is rejected)
-      uint64_t md = 0;
-      uint32_t hl = 0;
-      {
-        uint32_t shift = 0;
-        for (;;) {
-          if (q + hl >= q_end || hl >= 11) break;
-          uint32_t b = (uint32_t)((hl < 8 ? xlo >> (8u * hl) : xhi >> (8u * (hl - 8u))) & 0xFFu);
-          hl++;
-          if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
-          if ((b & 0x80u) == 0) break;
-          shift += 7;
+      const uint64_t remaining = n_values - produced;
+
+      T min_delta;
+      uint32_t wb, qp;
+      uint32_t st0, st1, st2, st3;
+      int mb_needed;
+      // Common case, kept short on the scalar unit (one scalar unit serves all waves of a CU, and this loop runs
+      // once per 128 values): a minimum delta of at most four varint bytes, a full block, every miniblock inside
+      // the stream, no width above 64.
+      const uint32_t x0 = (uint32_t)xlo;
+      const uint32_t stop = ~x0 & 0x80808080u;
+      bool hot = false;
+      if (__builtin_expect(stop != 0u && remaining >= 128u, 1)) {
+        const uint32_t hl = ((uint32_t)__builtin_ctz(stop) >> 3) + 1u;  // 1..4 varint bytes
+        uint32_t md32 = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u) | ((x0 >> 2) & 0x1FC000u) | ((x0 >> 3) & 0xFE00000u);
+        md32 &= 0xFFFFFFFFu >> (32u - 7u * hl);
+        wb = (uint32_t)(xlo >> (8u * hl));
+        st0 = q + hl + 4u;
+        st1 = st0 + 4u * (wb & 0xFFu);
+        st2 = st1 + 4u * ((wb >> 8) & 0xFFu);
+        st3 = st2 + 4u * ((wb >> 16) & 0xFFu);
+        qp = st3 + 4u * (wb >> 24);
+        const uint32_t over64 = (((wb & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) | wb) & 0x80808080u;  // some width byte >= 65
+        if (__builtin_expect(qp <= q_end && over64 == 0u, 1)) {
+          hot = true;
+          min_delta = DeltaTraits<T>::zigzag((uint64_t)md32);
+          mb_needed = 4;
         }
       }
-      if (hl >= 11) { status = PQD_ERR_MALFORMED; break; }
-      const T min_delta = DeltaTraits<T>::zigzag(md);
-      uint32_t qp = q + hl;
-      // the four width bytes: ReadByte at the end is io.EOF (encodingread.go:309-312)
-      if (qp + 4 > q_end) { status = PQD_ERR_EOF; break; }
-      uint32_t wb;
-      if (hl == 0) wb = (uint32_t)xlo;
-      else if (hl < 8) wb = (uint32_t)((xlo >> (8u * hl)) | (xhi << (64u - 8u * hl)));
-      else wb = (uint32_t)(xhi >> (8u * (hl - 8u)));
-      qp += 4;
-      const uint64_t remaining = n_values - produced;
-      const int mb_needed = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
-      uint32_t start[4];
-      uint32_t wmax = 0;
-      bool eof = false;
-      for (int m = 0; m < 4; m++) {
-        uint32_t wm = (wb >> (8 * m)) & 0xFFu;
-        start[m] = qp;
-        if (m < mb_needed) {
-          if (wm > wmax) wmax = wm;
-          if (wm > 0) {
-            if (qp >= q_end) { eof = true; break; }       // ReadBitPacked with nothing left
-            uint32_t nbytes = 4u * wm;
-            qp += nbytes < q_end - qp ? nbytes : q_end - qp;  // a short miniblock is zero filled
+      if (!hot) {
+        uint32_t d3 = __builtin_amdgcn_readfirstlane(ring[(di + 3) & (kRingDwords - 1)]);
+        uint32_t d4 = __builtin_amdgcn_readfirstlane(ring[(di + 4) & (kRingDwords - 1)]);
+        const uint64_t xhi = ((uint64_t)__builtin_amdgcn_alignbit(d4, d3, sh) << 32) | __builtin_amdgcn_alignbit(d3, d2, sh);
+        // minDelta varint (at most 10 bytes; a longer one is rejected)
+        uint64_t md = 0;
+        uint32_t hl = 0;
+        {
+          uint32_t shift = 0;
+          for (;;) {
+            if (q + hl >= q_end || hl >= 11) break;
+            uint32_t b = (uint32_t)((hl < 8 ? xlo >> (8u * hl) : xhi >> (8u * (hl - 8u))) & 0xFFu);
+            hl++;
+            if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
+            if ((b & 0x80u) == 0) break;
+            shift += 7;
           }
         }
+        if (hl >= 11) { status = PQD_ERR_MALFORMED; break; }
+        min_delta = DeltaTraits<T>::zigzag(md);
+        qp = q + hl;
+        // the four width bytes: ReadByte at the end is io.EOF (encodingread.go:309-312)
+        if (qp + 4 > q_end) { status = PQD_ERR_EOF; break; }
+        if (hl == 0) wb = (uint32_t)xlo;
+        else if (hl < 8) wb = (uint32_t)((xlo >> (8u * hl)) | (xhi << (64u - 8u * hl)));
+        else wb = (uint32_t)(xhi >> (8u * (hl - 8u)));
+        qp += 4;
+        mb_needed = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
+        uint32_t start[4];
+        uint32_t wmax = 0;
+        bool eof = false;
+        for (int m = 0; m < 4; m++) {
+          uint32_t wm = (wb >> (8 * m)) & 0xFFu;
+          start[m] = qp;
+          if (m < mb_needed) {
+            if (wm > wmax) wmax = wm;
+            if (wm > 0) {
+              if (qp >= q_end) { eof = true; break; }       // ReadBitPacked with nothing left
+              uint32_t nbytes = 4u * wm;
+              qp += nbytes < q_end - qp ? nbytes : q_end - qp;  // a short miniblock is zero filled
+            }
+          }
+        }
+        if (eof) { status = PQD_ERR_EOF; break; }
+        if (wmax > 64) { status = PQD_ERR_BIT_WIDTH; break; }
+        st0 = start[0]; st1 = start[1]; st2 = start[2]; st3 = start[3];
       }
-      if (eof) { status = PQD_ERR_EOF; break; }
-      if (wmax > 64) { status = PQD_ERR_BIT_WIDTH; break; }
       // unpack: lane -> miniblock lane/16, values 2*(lane%16) and +1
       const int m = lane >> 4;
       const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
       const uint32_t j0 = (uint32_t)(lane & 15) * 2u;
       T t0 = 0, t1 = 0;
       if (m < mb_needed) {
-        const uint32_t sm = m == 0 ? start[0] : m == 1 ? start[1] : m == 2 ? start[2] : start[3];
+        const uint32_t sm = m == 0 ? st0 : m == 1 ? st1 : m == 2 ? st2 : st3;
         uint64_t e0 = 0, e1 = 0;
         if (wm > 0) {
           e0 = ring_extract(ring, sm, j0 * wm, wm);
