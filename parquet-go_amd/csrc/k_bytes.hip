@@ -168,34 +168,49 @@ __global__ __launch_bounds__(1024) void k_scan_partials(int64_t *partial, int n_
   if (threadIdx.x == 0) partial[n_tiles] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, const int64_t *partial,
-                                                     int n_tiles, int64_t *doff) {
-  __shared__ int64_t s_scan[256];
-  const int64_t base = (int64_t)blockIdx.x * kScanTile;
-  const int tid = threadIdx.x;
-  // thread handles kScanTile / 256 consecutive values
-  constexpr int PER = kScanTile / 256;
-  int64_t ln[PER], sum = 0;
-  for (int k = 0; k < PER; k++) {
-    const int64_t i = base + (int64_t)tid * PER + k;
-    ln[k] = i < n ? value_len(pairs, prefix, i) : 0;
-    sum += ln[k];
+// Offsets of one tile: every wave takes a quarter of the tile, two neighbouring values per lane and step (128-bit
+// loads and stores that cover contiguous memory across the wave), a wave scan per step, the carry in a scalar.
+__global__ __launch_bounds__(256) void k_len_offsets(const uint64_t *__restrict__ pairs, const int64_t *__restrict__ prefix, int64_t n,
+                                                     const int64_t *__restrict__ partial, int n_tiles, int64_t *__restrict__ doff) {
+  __shared__ int64_t s_wave[4];
+  constexpr int kPerWave = kScanTile / 4, kSteps = kPerWave / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + wave * kPerWave;
+  int64_t l0[kSteps], l1[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const int64_t i = base + s * 128 + lane * 2;
+    l0[s] = 0; l1[s] = 0;
+    if (i + 1 < n) {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pairs + i);
+      l0[s] = (int64_t)(a.x >> 40); l1[s] = (int64_t)(a.y >> 40);
+      if (prefix) { const longlong2 q = *reinterpret_cast<const longlong2 *>(prefix + i); l0[s] += q.x; l1[s] += q.y; }
+    } else if (i < n) {
+      l0[s] = value_len(pairs, prefix, i);
+    }
   }
-  s_scan[tid] = sum;
+  // exclusive offsets inside the wave's quarter
+  int64_t carry = 0, ex[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    int64_t x = l0[s] + l1[s];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    ex[s] = carry + x - (l0[s] + l1[s]);
+    carry += __shfl(x, 63);
+  }
+  if (lane == 0) s_wave[wave] = carry;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    int64_t t = tid >= o ? s_scan[tid - o] : 0;
-    __syncthreads();
-    s_scan[tid] += t;
-    __syncthreads();
+  int64_t off = partial[blockIdx.x];
+  for (int w = 0; w < wave; w++) off += s_wave[w];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const int64_t i = base + s * 128 + lane * 2;
+    const int64_t o0 = off + ex[s];
+    if (i + 1 < n) *reinterpret_cast<longlong2 *>(doff + i) = longlong2{o0, o0 + l0[s]};
+    else if (i < n) doff[i] = o0;
   }
-  int64_t off = partial[blockIdx.x] + s_scan[tid] - sum;
-  for (int k = 0; k < PER; k++) {
-    const int64_t i = base + (int64_t)tid * PER + k;
-    if (i < n) doff[i] = off;
-    off += ln[k];
-  }
-  if (blockIdx.x == 0 && tid == 0) doff[n] = partial[n_tiles];
+  if (blockIdx.x == 0 && threadIdx.x == 0) doff[n] = partial[n_tiles];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,6 +286,8 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
     const int64_t pi = prefix[base + i];
     if (pi < 0 || pi > kMaxStrLen) bad = 1;
     else if (pi + (int64_t)(pairs[base + i] >> 40) > kChainMax) lng = 1;
+    // a prefix longer than the previous string is a slice out of range in the reference (encodingread.go:430)
+    if (i > 0 && pi > (i == 1 ? 0 : prefix[base + i - 1]) + (int64_t)(pairs[base + i - 1] >> 40)) bad = 1;
   }
   if (bad) s_bad = 1;
   if (lng) s_long = 1;
@@ -281,101 +298,141 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
   }
 }
 
-// Pages without long strings, one wavefront per page, strings in order: lane j carries byte j of the previous
-// string; byte j of the next one is that byte when j lies in the shared prefix, else a byte of the suffix.
-// Suffixes follow each other in the page and so do the outputs, so only the two lengths are per-string inputs.
-// The page is walked in batches of 64 strings: the suffix bytes of the next batch and the lengths of the one after
-// it are in flight while the current batch is chained together (one wave per page leaves nothing else to hide the
-// load latency behind).  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS.
+// Pages without long strings, strings in order: lane j carries byte j of the previous string; byte j of the next
+// one is that byte when j lies in the shared prefix, else a byte of the suffix.  Suffixes follow each other in the
+// page and so do the outputs, so only the two lengths are per-string inputs.
+//
+// A string with prefix length 0 does not depend on its predecessor: the page is cut into kChainWaves ranges that
+// each begin at such a string (the first one at or after an even split), one wavefront per range.  Data without
+// such strings leaves a page to one wavefront, at the speed of a single chain.
+//
+// A range is walked in batches of 64 strings (lane u holds the lengths of string u): the suffix bytes of the next
+// batch and the lengths of the one after it are in flight while the current batch is chained together.  The chain
+// costs issue slots, not bandwidth, so the per-string work is pared down to two lane reads, one select and two
+// buffer instructions: loads and stores go through buffer descriptors whose range check (offset register plus
+// lane offset against the record count, as gfx950 applies it) does the clipping that would otherwise need the
+// execution mask: a store only lands for lanes below the string's length, a load past the end of the chunk returns
+// zero.  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS instead.
 struct DbaBatch {
-  int P, S;            // this lane's string: prefix and suffix length
+  int P, L;            // this lane's string: prefix length and whole length
+  uint32_t ldoff;      // this lane's string: suffix start minus prefix length, relative to in_base
   int mx;              // longest string of the batch
+  int64_t in_base;     // chunk offset the batch's loads are relative to
   const uint8_t *src;  // suffix bytes of the batch, back to back
   uint8_t *out;        // output of the batch's first string
 };
 
-__global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int64_t *doff,
-                                                  const int32_t *page_flag, uint8_t *bytes_out) {
-  __shared__ uint8_t s_cur[kChainMax + 64];
-  const int d = blockIdx.x, lane = threadIdx.x;
+constexpr int kChainWaves = 8;
+constexpr int kRsrcFlags = 0x00020000;  // raw buffer, 32-bit data format
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane holds alike, moved to scalar registers
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(64 * kChainWaves) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
+                                                                const uint64_t *__restrict__ pairs, const int64_t *__restrict__ doff,
+                                                                const int32_t *__restrict__ page_flag, uint8_t *__restrict__ bytes_out) {
+  __shared__ uint8_t s_cur_all[kChainWaves][kChainMax + 64];
+  __shared__ int s_bnd[kChainWaves + 1];
+  const int d = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  uint8_t *s_cur = s_cur_all[wave];
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] != 0) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
-  const int64_t base = ps->dense_base;
-  const int cnt = ps->cnt;
+  const int64_t base = uniform64(ps->dense_base);
+  const int cnt = __builtin_amdgcn_readfirstlane(ps->cnt);
 
-  auto fetch_lengths = [&](int i0, int &P, int &S, uint64_t &pr0, int64_t &o0) {
-    P = 0; S = 0; pr0 = 0; o0 = 0;
-    if (i0 < cnt) {
-      if (i0 + lane < cnt) { P = (int)prefix[base + i0 + lane]; S = (int)(pairs[base + i0 + lane] >> 40); }
-      pr0 = pairs[base + i0];
-      o0 = doff[base + i0];
+  // this wave's range [r_lo, r_hi)
+  {
+    int lo = cnt;
+    const int from = wave == 0 ? 0 : (int)((int64_t)cnt * wave / kChainWaves);
+    for (int j0 = from; j0 < cnt && lo == cnt; j0 += 64) {
+      const int j = j0 + lane;
+      const bool zero = j < cnt && (j == 0 || prefix[base + j] == 0);
+      const uint64_t m = __ballot(zero);
+      if (m) lo = j0 + (int)__builtin_ctzll(m);
     }
+    if (lane == 0) s_bnd[wave] = lo;
+    if (threadIdx.x == 0) s_bnd[kChainWaves] = cnt;
+  }
+  __syncthreads();
+  const int r_lo = __builtin_amdgcn_readfirstlane(s_bnd[wave]);
+  if (wave > 0 && s_bnd[wave - 1] == r_lo) return;  // same start as the wave before: that wave does the range
+  int r_hi = cnt;
+  for (int k = kChainWaves - 1; k > wave; k--)
+    if (s_bnd[k] > r_lo) r_hi = s_bnd[k];            // starts never decrease with k
+  r_hi = __builtin_amdgcn_readfirstlane(r_hi);
+  if (r_lo >= r_hi) return;
+
+  struct Fetched { int P, S; uint64_t pr, pr0; int64_t o0; };
+  auto fetch_lengths = [&](int i0) {
+    Fetched f{0, 0, 0, 0, 0};
+    if (i0 < r_hi) {
+      if (i0 + lane < r_hi) { f.P = (int)prefix[base + i0 + lane]; f.pr = pairs[base + i0 + lane]; f.S = (int)(f.pr >> 40); }
+      f.pr0 = (uint64_t)uniform64((int64_t)pairs[base + i0]);
+      f.o0 = uniform64(doff[base + i0]);
+    }
+    return f;
   };
-  auto make_batch = [&](int P, int S, uint64_t pr0, int64_t o0) {
+  auto make_batch = [&](const Fetched &f) {
     DbaBatch b;
-    b.P = P; b.S = S;
-    int mx = P + S;
+    b.P = f.P; b.L = f.P + f.S;
+    int mx = b.L;
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-    b.mx = mx;
-    b.src = c.in + (pr0 & kSrcMask);
-    b.out = bytes_out + o0;
+    b.mx = __builtin_amdgcn_readfirstlane(mx);
+    const int64_t src0 = (int64_t)(f.pr0 & kSrcMask);
+    b.in_base = src0 > 64 ? src0 - 64 : 0;  // a prefix is at most 64 bytes here and never longer than the suffix bytes before it
+    b.ldoff = (uint32_t)((int64_t)(f.pr & kSrcMask) - b.in_base - f.P);
+    b.src = c.in + src0;
+    b.out = bytes_out + f.o0;
     return b;
   };
-  // the suffix byte of every string of a batch that falls on this lane (strings of at most 64 bytes)
-  auto issue_loads = [&](const DbaBatch &b, int nb, uint32_t ld[64]) {
+  // byte `lane` of every string of a batch, wherever it comes from (strings of at most 64 bytes); lanes outside
+  // the suffix load a neighbouring byte that the chain never selects
+  auto issue_loads = [&](const DbaBatch &b, uint32_t ld[64]) {
     if (b.mx > 64) return;
-    const uint8_t *sp = b.src;
+    const int64_t left = c.in_len - b.in_base;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(c.in + b.in_base), 0, left > 0x7fffffff ? 0x7fffffff : (int)left, kRsrcFlags);
 #pragma unroll
-    for (int u = 0; u < 64; u++) {
-      const int pk = __builtin_amdgcn_readlane(b.P, u), sk = __builtin_amdgcn_readlane(b.S, u);  // lanes beyond nb hold 0, 0
-      ld[u] = 0;
-      if (lane >= pk && lane < pk + sk) ld[u] = sp[lane - pk];
-      sp += sk;
-    }
-    (void)nb;
+    for (int u = 0; u < 64; u++)
+      ld[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, lane, (int)__builtin_amdgcn_readlane(b.ldoff, u), 0);
   };
 
   uint32_t cur = 0;   // byte `lane` of the previous string
-  int len_prev = 0;
   uint32_t ld_a[64], ld_b[64];
-  int P1, S1, P2, S2;
-  uint64_t pr1, pr2;
-  int64_t o1, o2;
-  fetch_lengths(0, P1, S1, pr1, o1);
-  DbaBatch cb = make_batch(P1, S1, pr1, o1);
-  issue_loads(cb, cnt < 64 ? cnt : 64, ld_a);
-  fetch_lengths(64, P1, S1, pr1, o1);
-  for (int i0 = 0; i0 < cnt; i0 += 64) {
-    const int nb = cnt - i0 < 64 ? cnt - i0 : 64;
+  Fetched f1 = fetch_lengths(r_lo);
+  DbaBatch cb = make_batch(f1);
+  issue_loads(cb, ld_a);
+  f1 = fetch_lengths(r_lo + 64);
+  for (int i0 = r_lo; i0 < r_hi; i0 += 64) {
+    const int nb = r_hi - i0 < 64 ? r_hi - i0 : 64;
     // next batch: its byte loads go out now; the lengths of the batch after it too
-    const DbaBatch nbatch = make_batch(P1, S1, pr1, o1);
-    const int nb_next = cnt - (i0 + 64) < 64 ? cnt - (i0 + 64) : 64;
-    if (i0 + 64 < cnt) issue_loads(nbatch, nb_next, ld_b);
-    fetch_lengths(i0 + 128, P2, S2, pr2, o2);
+    const DbaBatch nbatch = make_batch(f1);
+    if (i0 + 64 < r_hi) issue_loads(nbatch, ld_b);
+    const Fetched f2 = fetch_lengths(i0 + 128);
 
-    const uint8_t *src = cb.src;
-    uint8_t *out = cb.out;
     if (cb.mx <= 64) {
-      bool bad = false;
+      // (lanes beyond the batch hold lengths 0, 0: nothing is written for them)
+      uint32_t soff = 0;
 #pragma unroll
       for (int u = 0; u < 64; u++) {
-        // (lanes beyond the batch hold lengths 0, 0: nothing is written for them)
-        const int pk = __builtin_amdgcn_readlane(cb.P, u), sk = __builtin_amdgcn_readlane(cb.S, u);
-        bad = bad || (u < nb && pk > len_prev);  // slice beyond the previous string
-        const uint32_t b = lane < pk ? cur : ld_a[u];
-        if (!bad && lane < pk + sk) { out[lane] = (uint8_t)b; cur = b; }
-        out += pk + sk;
-        if (u < nb) len_prev = pk + sk;
+        const int pk = __builtin_amdgcn_readlane(cb.P, u), len = __builtin_amdgcn_readlane(cb.L, u);
+        cur = lane < pk ? cur : ld_a[u];
+        const uint32_t nxt = soff + (uint32_t)len;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(cb.out, 0, (int)nxt, kRsrcFlags);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cur, ro, lane, (int)soff, 0);
+        soff = nxt;
       }
-      if (bad) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
     } else {
+      const uint8_t *src = cb.src;
+      uint8_t *out = cb.out;
       s_cur[lane] = (uint8_t)cur;
       for (int k = 0; k < nb; k++) {
-        const int pk = __builtin_amdgcn_readlane(cb.P, k), sk = __builtin_amdgcn_readlane(cb.S, k);
-        if (pk > len_prev) { if (lane == 0) set_status_b(&ps->status, PQD_ERR_MALFORMED); return; }
-        const int len = pk + sk;
+        const int pk = __builtin_amdgcn_readlane(cb.P, k), len = __builtin_amdgcn_readlane(cb.L, k);
         for (int j = lane; j < len; j += 64) {
           uint8_t b;
           if (j >= pk) { b = src[j - pk]; s_cur[j] = b; }
@@ -383,9 +440,8 @@ __global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *pre
           out[j] = b;
         }
         __builtin_amdgcn_wave_barrier();
-        src += sk;
+        src += len - pk;
         out += len;
-        len_prev = len;
       }
       cur = s_cur[lane];
     }
@@ -393,7 +449,7 @@ __global__ __launch_bounds__(64) void k_dba_chain(ChunkCtx c, const int64_t *pre
     cb = nbatch;
 #pragma unroll
     for (int u = 0; u < 64; u++) ld_a[u] = ld_b[u];
-    P1 = P2; S1 = S2; pr1 = pr2; o1 = o2;
+    f1 = f2;
   }
 }
 
@@ -554,7 +610,7 @@ hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t
     hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag);
     hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent, page_flag);
   } else {
-    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out);
+    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out);
     hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out);
   }
   return hipGetLastError();
