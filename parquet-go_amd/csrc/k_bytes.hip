@@ -307,12 +307,11 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 // such strings leaves a page to one wavefront, at the speed of a single chain.
 //
 // A range is walked in batches of 64 strings (lane u holds the lengths of string u): the suffix bytes of the next
-// batch and the lengths of the one after it are in flight while the current batch is chained together.  The chain
-// costs issue slots, not bandwidth, so the per-string work is pared down to two lane reads, one select and two
-// buffer instructions: loads and stores go through buffer descriptors whose range check (offset register plus
-// lane offset against the record count, as gfx950 applies it) does the clipping that would otherwise need the
-// execution mask: a store only lands for lanes below the string's length, a load past the end of the chunk returns
-// zero.  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS instead.
+// half batch and the lengths of the batch after the next are in flight while the current half is chained together.
+// The chain costs issue slots, not bandwidth, so the per-string work is pared down to three lane reads, one select,
+// one buffer load and one LDS write.  The loads go through a buffer descriptor (offset register plus lane offset,
+// checked against the record count as gfx950 does): one past the end of the chunk returns zero, and no execution
+// mask is needed.  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS instead.
 struct DbaBatch {
   int P, L;            // this lane's string: prefix length and whole length
   uint32_t ldoff;      // this lane's string: suffix start minus prefix length, relative to in_base
@@ -323,6 +322,7 @@ struct DbaBatch {
 };
 
 constexpr int kChainWaves = 8;
+constexpr int kStageBytes = 32 * 64 + 16 + 64 + 48;  // half a batch of 64-byte strings, the misalignment, the last string's overhang
 constexpr int kRsrcFlags = 0x00020000;  // raw buffer, 32-bit data format
 
 __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane holds alike, moved to scalar registers
@@ -330,14 +330,16 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(64 * kChainWaves) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
+__global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
                                                                 const uint64_t *__restrict__ pairs, const int64_t *__restrict__ doff,
                                                                 const int32_t *__restrict__ page_flag, uint8_t *__restrict__ bytes_out) {
   __shared__ uint8_t s_cur_all[kChainWaves][kChainMax + 64];
+  __shared__ __align__(16) uint8_t s_stage_all[kChainWaves][kStageBytes];
   __shared__ int s_bnd[kChainWaves + 1];
   const int d = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint8_t *s_cur = s_cur_all[wave];
+  uint8_t *stage = s_stage_all[wave];
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] != 0) return;
   PageState *ps = &c.state[p];
@@ -390,44 +392,75 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_dba_chain(ChunkCtx c, cons
     b.out = bytes_out + f.o0;
     return b;
   };
-  // byte `lane` of every string of a batch, wherever it comes from (strings of at most 64 bytes); lanes outside
-  // the suffix load a neighbouring byte that the chain never selects
-  auto issue_loads = [&](const DbaBatch &b, uint32_t ld[64]) {
+  // byte `lane` of every string of half a batch, wherever it comes from (strings of at most 64 bytes); lanes
+  // outside the suffix load a neighbouring byte that the chain never selects
+  auto issue_loads = [&](const DbaBatch &b, int half, uint32_t ld[32]) {
     if (b.mx > 64) return;
     const int64_t left = c.in_len - b.in_base;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(c.in + b.in_base), 0, left > 0x7fffffff ? 0x7fffffff : (int)left, kRsrcFlags);
+    if (half == 0) {
 #pragma unroll
-    for (int u = 0; u < 64; u++)
-      ld[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, lane, (int)__builtin_amdgcn_readlane(b.ldoff, u), 0);
+      for (int u = 0; u < 32; u++) ld[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, lane, (int)__builtin_amdgcn_readlane(b.ldoff, u), 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 32; u++) ld[u] = __builtin_amdgcn_raw_buffer_load_b8(rs, lane, (int)__builtin_amdgcn_readlane(b.ldoff, u + 32), 0);
+    }
+  };
+  // Half a batch is chained into an LDS staging area, every string written whole-wave at its offset (the bytes a
+  // string writes beyond its length are overwritten by its successors, LDS operations of a wave being executed in
+  // order), and leaves for memory as 128-bit stores; the staging area starts at the output's misalignment so that
+  // LDS and memory chunks coincide, and the partial chunks at both ends go out bytewise.
+  // (lanes beyond the batch hold lengths 0, 0: nothing is kept for them)
+  uint32_t cur = 0;   // byte `lane` of the previous string
+  auto chain_half = [&](const DbaBatch &b, int half, const uint32_t ld[32], uint32_t out_off) {
+    uint8_t *dst = b.out + out_off;
+    const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(dst) & 15u;
+    uint8_t *wp = stage + a + lane;
+    uint32_t total = 0;
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      const int pk = __builtin_amdgcn_readlane(b.P, half ? u + 32 : u), len = __builtin_amdgcn_readlane(b.L, half ? u + 32 : u);
+      cur = lane < pk ? cur : ld[u];
+      *wp = (uint8_t)cur;
+      wp += len;
+      total += (uint32_t)len;
+    }
+    const uint32_t end = a + total;
+    uint8_t *g0 = dst - a;
+    const uint32_t n_chunks = (end + 15) >> 4;
+    for (uint32_t j = lane; j < n_chunks; j += 64) {
+      const uint32_t lo = 16 * j;
+      if (lo >= a && lo + 16 <= end) *reinterpret_cast<uint4 *>(g0 + lo) = *reinterpret_cast<const uint4 *>(stage + lo);
+    }
+    // first chunk (lanes 0-15) and last chunk (lanes 16-31) when they are partial
+    {
+      const uint32_t last = n_chunks ? 16 * (n_chunks - 1) : 0;
+      const uint32_t pos = lane < 16 ? lane : last + (lane - 16);
+      const bool head = lane < 16 && (a != 0 || end < 16);
+      const bool tail = lane >= 16 && lane < 32 && n_chunks > 1 && (end & 15) != 0;
+      if ((head || tail) && pos >= a && pos < end) g0[pos] = stage[pos];
+    }
+    return out_off + total;
   };
 
-  uint32_t cur = 0;   // byte `lane` of the previous string
-  uint32_t ld_a[64], ld_b[64];
+  // the byte loads run half a batch ahead of the chain, the lengths two batches ahead
+  uint32_t ld_a[32], ld_b[32];
   Fetched f1 = fetch_lengths(r_lo);
   DbaBatch cb = make_batch(f1);
-  issue_loads(cb, ld_a);
+  issue_loads(cb, 0, ld_a);
   f1 = fetch_lengths(r_lo + 64);
   for (int i0 = r_lo; i0 < r_hi; i0 += 64) {
     const int nb = r_hi - i0 < 64 ? r_hi - i0 : 64;
-    // next batch: its byte loads go out now; the lengths of the batch after it too
     const DbaBatch nbatch = make_batch(f1);
-    if (i0 + 64 < r_hi) issue_loads(nbatch, ld_b);
     const Fetched f2 = fetch_lengths(i0 + 128);
-
     if (cb.mx <= 64) {
-      // (lanes beyond the batch hold lengths 0, 0: nothing is written for them)
-      uint32_t soff = 0;
-#pragma unroll
-      for (int u = 0; u < 64; u++) {
-        const int pk = __builtin_amdgcn_readlane(cb.P, u), len = __builtin_amdgcn_readlane(cb.L, u);
-        cur = lane < pk ? cur : ld_a[u];
-        const uint32_t nxt = soff + (uint32_t)len;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(cb.out, 0, (int)nxt, kRsrcFlags);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cur, ro, lane, (int)soff, 0);
-        soff = nxt;
-      }
+      if (nb > 32) issue_loads(cb, 1, ld_b);
+      const uint32_t mid = chain_half(cb, 0, ld_a, 0);
+      if (i0 + 64 < r_hi) issue_loads(nbatch, 0, ld_a);
+      if (nb > 32) chain_half(cb, 1, ld_b, mid);
     } else {
+      if (i0 + 64 < r_hi) issue_loads(nbatch, 0, ld_a);
       const uint8_t *src = cb.src;
       uint8_t *out = cb.out;
       s_cur[lane] = (uint8_t)cur;
@@ -445,10 +478,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_dba_chain(ChunkCtx c, cons
       }
       cur = s_cur[lane];
     }
-    // rotate
     cb = nbatch;
-#pragma unroll
-    for (int u = 0; u < 64; u++) ld_a[u] = ld_b[u];
     f1 = f2;
   }
 }
