@@ -17,3 +17,5 @@ echo "FETCH_SIZE pass done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" $SHORT > "$OUT/write.json" 2> "$OUT/write.err" || { echo "WRITE_SIZE pass failed"; tail -5 "$OUT/write.err"; exit 1; }
 echo "WRITE_SIZE pass done"
 cd "$R" && python3 profiles/summarize.py "$OUT" "$TAG"
+# the box's profiles/ does not travel back; gpurun_out/ does
+mkdir -p "$R/gpurun_out/profiles_$TAG" && cp "$R"/profiles/${TAG}_*.csv "$R"/profiles/traffic.json "$R/gpurun_out/profiles_$TAG/"
