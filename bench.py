@@ -380,8 +380,19 @@ def run_extras(args, dec, local_rank):
             assert t.status == 0
             best = dt if best is None else min(best, dt)
         extra["host_to_host"] = {"workload": "INT32 RLE_DICTIONARY w=12, %d Mi values: host bytes -> pinned staging -> H2D -> decode "
-                                             "-> D2H into pageable numpy" % (n >> 20),
+                                             "-> D2H into freshly allocated pageable numpy arrays (values and both level arrays)" % (n >> 20),
                                  "decoded_GBps": round(n * 4 / best / 1e9, 2), "ms": round(best * 1e3, 2)}
+        best = None
+        for i in range(3):
+            t0 = time.perf_counter()
+            dec.submit(chunk, pages, pq.INT32)
+            t = dec.fetch_pinned()
+            dt = time.perf_counter() - t0
+            assert t.status == 0
+            best = dt if best is None else min(best, dt)
+        extra["host_to_pinned"] = {"workload": "same chunk, result left in the handle's page-locked memory (pqd_result_host) "
+                                               "for the caller to read in place",
+                                   "decoded_GBps": round(n * 4 / best / 1e9, 2), "ms": round(best * 1e3, 2)}
     except Exception as e:
         extra["host_to_host"] = {"error": repr(e)}
     return extra

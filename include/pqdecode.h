@@ -189,6 +189,13 @@ int pqd_result_device(pqd_handle *h, pqd_device_result *out);
 int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_levels, int64_t *offsets,
                  uint8_t *bytes);
 
+/* The last result in page-locked host memory owned by the handle (valid until its next decode call): the same
+ * arrays as pqd_device_result, moved by DMA at link speed instead of through a bounce buffer into pageable
+ * memory.  The caller reads them in place (the Go shim boxes layout.Table.Values straight from them,
+ * layout/table.go:28-49) or copies what it keeps.  Level pointers are NULL when the column has no such level.
+ * Fields of pqd_device_result carry host addresses here. */
+int pqd_result_host(pqd_handle *h, pqd_device_result *out);
+
 /* Row index of the last decoded chunk: entry r = slot at which row r begins (a slot with repetition level 0; every
  * slot when max_rep is 0), entry num_rows = num_slots.  With it the caller cuts the typed arrays at row boundaries
  * the way Table.Pop does (layout/table.go:73-103: the first n rows are the slots before the (n+1)-th slot with

@@ -115,26 +115,30 @@ func (h *Handle) DecodeChunk(chunk []byte, numValues int64, col Column) (*layout
 	if slots == 0 {
 		return t, 0, nil
 	}
-	dl := (*C.int32_t)(unsafe.Pointer(&t.DefinitionLevels[0]))
-	rl := (*C.int32_t)(unsafe.Pointer(&t.RepetitionLevels[0]))
+	// The result is read in place from the handle's page-locked memory (valid until the handle's next decode call):
+	// the level arrays are copied into the Table, the values are boxed straight from it.
+	var hr C.pqd_device_result
+	if rc := C.pqd_result_host(h.h, &hr); rc != 0 {
+		return nil, 0, libErr(rc, -1)
+	}
+	if hr.def_levels != nil {
+		copy(t.DefinitionLevels, unsafe.Slice((*int32)(unsafe.Pointer(hr.def_levels)), slots))
+	}
+	if hr.rep_levels != nil {
+		copy(t.RepetitionLevels, unsafe.Slice((*int32)(unsafe.Pointer(hr.rep_levels)), slots))
+	}
 	if col.Type == parquet.Type_BYTE_ARRAY {
-		offs := make([]int64, slots+1)
-		buf := make([]byte, int(res.bytes_len)+1)
-		if rc := C.pqd_copy_out(h.h, nil, dl, rl, (*C.int64_t)(unsafe.Pointer(&offs[0])), (*C.uint8_t)(unsafe.Pointer(&buf[0]))); rc != 0 {
-			return nil, 0, libErr(rc, -1)
-		}
+		offs := unsafe.Slice((*int64)(unsafe.Pointer(hr.offsets)), slots+1)
+		buf := unsafe.Slice((*byte)(unsafe.Pointer(hr.bytes)), int(res.bytes_len))
 		for i := 0; i < slots; i++ {
 			if t.DefinitionLevels[i] == col.MaxDef {
-				t.Values[i] = string(buf[offs[i]:offs[i+1]]) // the reference holds BYTE_ARRAY values as string
+				t.Values[i] = string(buf[offs[i]:offs[i+1]]) // copies; the reference holds BYTE_ARRAY values as string
 			}
 		}
 		return t, int64(res.num_rows), nil
 	}
 	esz := int(res.elem_size)
-	raw := make([]byte, slots*esz+1)
-	if rc := C.pqd_copy_out(h.h, unsafe.Pointer(&raw[0]), dl, rl, nil, nil); rc != 0 {
-		return nil, 0, libErr(rc, -1)
-	}
+	raw := unsafe.Slice((*byte)(hr.values), slots*esz)
 	box(t, raw, esz, col)
 	return t, int64(res.num_rows), nil
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "pqd_version", "pqd_last_error", "pqd_strerror", "pqd_device_count", "pqd_handle_create",
     "pqd_handle_destroy", "pqd_set_profiling", "pqd_scan_pages", "pqd_decode_chunk",
     "pqd_decode_chunk_device", "pqd_wait", "pqd_result_device", "pqd_copy_out", "pqd_page_counts",
-    "pqd_kernel_times", "pqd_decode_levels", "pqd_decode_levels_device", "pqd_row_starts",
+    "pqd_kernel_times", "pqd_decode_levels", "pqd_decode_levels_device", "pqd_row_starts", "pqd_result_host",
 ]
 
 
@@ -100,6 +100,7 @@ def lib():
         L.pqd_row_starts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.pqd_wait.argtypes = [C.c_void_p, C.POINTER(_ChunkResult)]
         L.pqd_result_device.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
+        L.pqd_result_host.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
         L.pqd_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pqd_page_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.pqd_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -274,6 +275,36 @@ class Decoder:
             pc = np.zeros((self._pages.size, 3), np.int64)
             _check(lib().pqd_page_counts(self._h, C.c_void_p(pc.ctypes.data), self._pages.size))
             t.page_counts = pc
+        return t
+
+    def fetch_pinned(self, r=None):
+        """Wait and return the typed table as numpy views of the handle's page-locked result memory (no copy into
+        pageable arrays).  The views are valid until this decoder's next decode call."""
+        r = r or self.wait()
+        t = Table()
+        t.status, t.bad_page = r.status, r.bad_page
+        if r.status != 0:
+            return t
+        n = r.num_slots
+        t.n_slots, t.n_rows, t.n_nulls, t.n_values = n, r.num_rows, r.num_nulls, r.num_values
+        d = _DeviceResult()
+        _check(lib().pqd_result_host(self._h, C.byref(d)))
+
+        def view(addr, count, dtype):
+            if not addr or count == 0:
+                return np.zeros(count, dtype)
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(addr), dtype=dtype, count=count)
+
+        t.def_levels = view(d.def_levels, n, np.int32)
+        t.rep_levels = view(d.rep_levels, n, np.int32)
+        if self._is_bytes:
+            t.kind = "bytes"
+            t.offsets = view(d.offsets, n + 1, np.int64)
+            t.bytes = view(d.bytes, r.bytes_len, np.uint8)
+        else:
+            t.kind = "fixed"
+            t.values = view(d.values, n * r.elem_size, np.uint8).reshape(n, r.elem_size)
         return t
 
     _is_bytes = False

@@ -85,7 +85,7 @@ struct pqd_handle {
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
   DevBuf row_starts, dba_flags;
   int64_t bytes_len = 0;
-  PinnedBuf stage_in, stage_meta, host_small;
+  PinnedBuf stage_in, stage_out, stage_meta, host_small;
 
   // description of the last decode call
   std::vector<PageIn> h_pages;
@@ -615,7 +615,7 @@ int pqd_handle_destroy(pqd_handle *h) {
                     &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
                     &h->doff, &h->dict_pairs, &h->tile_desc, &h->row_starts, &h->dba_flags};
   for (DevBuf *b : bufs) b->release();
-  h->stage_in.release(); h->stage_meta.release(); h->host_small.release();
+  h->stage_in.release(); h->stage_out.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PQD_OK;
@@ -728,6 +728,38 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
     else std::memset(rep_levels, 0, 4 * n);
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
+int pqd_result_host(pqd_handle *h, pqd_device_result *out) {
+  if (!h || !out) return fail_arg("NULL argument");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  Guard g(h->device);
+  *out = pqd_device_result{};
+  const size_t n = (size_t)h->total_slots;
+  const bool is_bytes = h->col.physical_type == PQD_BYTE_ARRAY;
+  const bool with_values = !h->levels_only && !(is_bytes && h->result.status != PQD_OK);
+  const size_t val_bytes = with_values ? (is_bytes ? 8 * (n + 1) : n * (size_t)h->elem_size) : 0;
+  const size_t byte_bytes = with_values && is_bytes ? (size_t)h->bytes_len : 0;
+  const size_t lvl_bytes = 4 * n;
+  // one pinned block: values or offsets | bytes | def | rep, each part 256-byte aligned
+  const size_t o_bytes = align_up(val_bytes, 256), o_def = o_bytes + align_up(byte_bytes, 256);
+  const size_t o_rep = o_def + (h->col.max_def > 0 ? align_up(lvl_bytes, 256) : 0);
+  const size_t total = o_rep + (h->col.max_rep > 0 ? align_up(lvl_bytes, 256) : 0);
+  int rc;
+  if ((rc = h->stage_out.ensure(total + 256))) return rc;
+  uint8_t *m = static_cast<uint8_t *>(h->stage_out.p);
+  if (val_bytes) HIP_TRY(hipMemcpyAsync(m, is_bytes ? h->offsets.p : h->values.p, val_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (byte_bytes) HIP_TRY(hipMemcpyAsync(m + o_bytes, h->bytes.p, byte_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (h->col.max_def > 0 && n) HIP_TRY(hipMemcpyAsync(m + o_def, h->def.p, lvl_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (h->col.max_rep > 0 && n) HIP_TRY(hipMemcpyAsync(m + o_rep, h->rep.p, lvl_bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (with_values) {
+    if (is_bytes) { out->offsets = reinterpret_cast<int64_t *>(m); out->bytes = m + o_bytes; }
+    else out->values = m;
+  }
+  if (h->col.max_def > 0) out->def_levels = reinterpret_cast<int32_t *>(m + o_def);
+  if (h->col.max_rep > 0) out->rep_levels = reinterpret_cast<int32_t *>(m + o_rep);
   return PQD_OK;
 }
 

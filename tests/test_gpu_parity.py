@@ -38,6 +38,14 @@ def check_same(dec, oracle, chunk, pages, ptype, type_length=0, max_def=0, max_r
     else:
         assert np.array_equal(g.offsets, o.offsets)
         assert np.array_equal(g.bytes, o.bytes)
+    # the same result read in place from the handle's page-locked memory
+    h = dec.fetch_pinned()
+    assert h.status == 0 and h.kind == g.kind and (h.n_slots, h.n_rows, h.n_nulls) == (g.n_slots, g.n_rows, g.n_nulls)
+    assert np.array_equal(h.def_levels, g.def_levels) and np.array_equal(h.rep_levels, g.rep_levels)
+    if g.kind == "fixed":
+        assert np.array_equal(h.values, g.values)
+    else:
+        assert np.array_equal(h.offsets, g.offsets) and np.array_equal(h.bytes, g.bytes)
     return g, o
 
 
