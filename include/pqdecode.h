@@ -164,6 +164,12 @@ int pqd_footer_chunk(const pqd_footer *f, int32_t i, pqd_chunk_desc *out);
 int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages,
                      int32_t n_pages, const pqd_column_desc *col);
 
+/* Page-locked input buffer of the handle, at least len bytes: a caller that reads the chunk from the file straight
+ * into it (the io.ReadFull of reader/columnbuffer.go:105-156's callers) and passes the same pointer to
+ * pqd_decode_chunk / pqd_decode_levels saves the copy into staging.  Valid until the next pqd_input_buffer call
+ * with a larger len; write to it only after pqd_wait of the handle's previous decode. */
+int pqd_input_buffer(pqd_handle *h, size_t len, uint8_t **buf);
+
 /* Same, chunk bytes already in device memory.  d_chunk must be 16-byte aligned and readable up to
  * len rounded up to a multiple of 16 (any hipMalloc / torch allocation is). */
 int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages,

@@ -143,6 +143,18 @@ func (h *Handle) DecodeChunk(chunk []byte, numValues int64, col Column) (*layout
 	return t, int64(res.num_rows), nil
 }
 
+// InputBuffer returns n bytes of the handle's page-locked input buffer.  A caller that reads the chunk from the file
+// straight into it (io.ReadFull(pFile, buf)) and passes the same slice to DecodeChunk saves one copy of the chunk;
+// the memory belongs to the library, so no Go pointer is involved.  Fill it only when the handle's previous
+// DecodeChunk has returned.
+func (h *Handle) InputBuffer(n int) ([]byte, error) {
+	var p *C.uint8_t
+	if rc := C.pqd_input_buffer(h.h, C.size_t(n), &p); rc != 0 {
+		return nil, libErr(rc, -1)
+	}
+	return unsafe.Slice((*byte)(unsafe.Pointer(p)), n), nil
+}
+
 // box fills Table.Values with the boxed Go values the reference's decoders produce (encoding/encodingread.go:13-125:
 // bool, int32, int64, string of 12 bytes for INT96, float32, float64, string for FIXED_LEN_BYTE_ARRAY), nil where the
 // definition level is below the maximum (layout/page.go:905-923).

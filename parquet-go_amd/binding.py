@@ -23,6 +23,7 @@ EXPORTS = [
     "pqd_handle_destroy", "pqd_set_profiling", "pqd_scan_pages", "pqd_decode_chunk",
     "pqd_decode_chunk_device", "pqd_wait", "pqd_result_device", "pqd_copy_out", "pqd_page_counts",
     "pqd_kernel_times", "pqd_decode_levels", "pqd_decode_levels_device", "pqd_row_starts", "pqd_result_host",
+    "pqd_input_buffer",
 ]
 
 
@@ -101,6 +102,7 @@ def lib():
         L.pqd_wait.argtypes = [C.c_void_p, C.POINTER(_ChunkResult)]
         L.pqd_result_device.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
         L.pqd_result_host.argtypes = [C.c_void_p, C.POINTER(_DeviceResult)]
+        L.pqd_input_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.pqd_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pqd_page_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.pqd_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -207,6 +209,7 @@ class Decoder:
         a = np.frombuffer(chunk, dtype=np.uint8) if not isinstance(chunk, np.ndarray) else np.ascontiguousarray(chunk, np.uint8)
         pg = np.ascontiguousarray(pages, dtype=PAGE_DESC_DTYPE)
         self._pages, self._keep = pg, a
+        self._is_bytes = physical_type == BYTE_ARRAY
         cd = self._col(physical_type, type_length, max_def, max_rep)
         _check(lib().pqd_decode_chunk(self._h, C.c_void_p(a.ctypes.data if a.size else None), a.size,
                                       C.c_void_p(pg.ctypes.data if pg.size else None), pg.size, C.byref(cd)))
@@ -215,6 +218,7 @@ class Decoder:
         """Chunk bytes already in device memory (16-byte aligned pointer)."""
         pg = np.ascontiguousarray(pages, dtype=PAGE_DESC_DTYPE)
         self._pages = pg
+        self._is_bytes = physical_type == BYTE_ARRAY
         cd = self._col(physical_type, type_length, max_def, max_rep)
         _check(lib().pqd_decode_chunk_device(self._h, C.c_void_p(dev_ptr), nbytes,
                                              C.c_void_p(pg.ctypes.data if pg.size else None), pg.size, C.byref(cd)))
@@ -276,6 +280,12 @@ class Decoder:
             _check(lib().pqd_page_counts(self._h, C.c_void_p(pc.ctypes.data), self._pages.size))
             t.page_counts = pc
         return t
+
+    def input_buffer(self, nbytes):
+        """numpy view (uint8, nbytes) of the handle's page-locked input buffer: fill it and pass it to submit()."""
+        p = C.c_void_p()
+        _check(lib().pqd_input_buffer(self._h, nbytes, C.byref(p)))
+        return np.frombuffer((C.c_uint8 * max(nbytes, 1)).from_address(p.value), dtype=np.uint8, count=nbytes)
 
     def fetch_pinned(self, r=None):
         """Wait and return the typed table as numpy views of the handle's page-locked result memory (no copy into

@@ -634,6 +634,16 @@ int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, cons
   return decode_on_device(h, static_cast<const uint8_t *>(d_chunk), len, pages, n_pages, col);
 }
 
+int pqd_input_buffer(pqd_handle *h, size_t len, uint8_t **buf) {
+  if (!h || !buf) return fail_arg("NULL argument");
+  Guard g(h->device);
+  int rc;
+  if (h->busy) HIP_TRY(hipStreamSynchronize(h->stream));  // a decode in flight may still be reading the buffer
+  if ((rc = h->stage_in.ensure(align_up(len + 64, 256)))) return rc;
+  *buf = static_cast<uint8_t *>(h->stage_in.p);
+  return PQD_OK;
+}
+
 int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
                      const pqd_column_desc *col) {
   if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !chunk)) return fail_arg("NULL argument");
@@ -642,8 +652,10 @@ int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_
   const size_t padded = align_up(len + 64, 256);
   if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
   // the caller's memory may not be retained (cgo rule): copy into pinned staging, then DMA
-  HIP_TRY(hipStreamSynchronize(h->stream));  // the previous chunk may still be reading the staging buffer
-  std::memcpy(h->stage_in.p, chunk, len);
+  if (chunk != h->stage_in.p) {                // (bytes already in the handle's input buffer are sent as they are)
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the previous chunk may still be reading the staging buffer
+    std::memcpy(h->stage_in.p, chunk, len);
+  }
   std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
   HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
   return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col);
@@ -663,8 +675,10 @@ int pqd_decode_levels(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd
   int rc;
   const size_t padded = align_up(len + 64, 256);
   if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  std::memcpy(h->stage_in.p, chunk, len);
+  if (chunk != h->stage_in.p) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(h->stage_in.p, chunk, len);
+  }
   std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
   HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
   return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col, true);

@@ -284,6 +284,25 @@ def test_levels_only_skip_path(dec, oracle, ptype):
     assert g.status == o.status != 0 and g.bad_page == o.bad_page
 
 
+def test_chunk_read_into_the_handles_input_buffer(dec, oracle):
+    # pqd_input_buffer: the caller fills the handle's page-locked buffer and passes that pointer (no staging copy);
+    # a larger request may move the buffer, a smaller one reuses it
+    rng = np.random.default_rng(77)
+    for n in (5000, 200000, 300):
+        cb = pg.ChunkBuilder(gap=3)
+        cb.dict_page(rand_dict(rng, pg.INT64, 500), 500)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, 500, n), 9, rng, "mixed"))
+        cb.data_page_v1(pg.ENC_PLAIN, n, rng.integers(-2**62, 2**62, n, dtype=np.int64).tobytes())
+        chunk, pages = cb.finish()
+        raw = np.frombuffer(chunk, np.uint8)
+        buf = dec.input_buffer(raw.size)
+        buf[:] = raw
+        dec.submit(buf, pages, pg.INT64)
+        g = dec.fetch_pinned()
+        o = oracle.read_chunk(chunk, pages, pg.INT64, 0, 0, 0)
+        assert g.status == o.status == 0 and np.array_equal(g.values, o.values)
+
+
 def test_delta_byte_array_length_classes(dec, oracle):
     # pages of short strings (one 64-byte row of lanes), of strings up to 1 KiB (previous string kept in LDS) and with
     # longer ones (parent-chain kernels), batches that mix the first two, and a prefix that overruns its predecessor
