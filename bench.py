@@ -64,11 +64,18 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal of the launch path) ranks share devices and
+    # PQD_BENCH_BACKEND=gloo carries the barriers, since RCCL refuses two ranks on one device
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("PQD_BENCH_BACKEND", "nccl")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     widths = [int(x) for x in args.widths.split(",")]
     n_values, page_values = args.values, args.page_values
 
@@ -171,9 +178,9 @@ def main():
         step(collect=collect_flag[0])
 
     dist = torch.distributed if world > 1 else None
-    sharding.timed_region(one_step, 0, args.warmup, sync=torch.cuda.synchronize, dist=dist, device="cuda", drain=drain)
+    sharding.timed_region(one_step, 0, args.warmup, sync=torch.cuda.synchronize, dist=dist, device=red_dev, drain=drain)
     collect_flag[0] = True
-    elapsed = sharding.timed_region(one_step, args.steps, 0, sync=torch.cuda.synchronize, dist=dist, device="cuda",
+    elapsed = sharding.timed_region(one_step, args.steps, 0, sync=torch.cuda.synchronize, dist=dist, device=red_dev,
                                     drain=lambda: drain(True))
 
     out_bytes_step = len(widths) * n_values * 4
