@@ -39,6 +39,11 @@ extern "C" {
 #define PQD_ERR_NOMEM (-10)
 #define PQD_ERR_NO_DICTIONARY (-11)        /* dictionary-encoded data page without a dictionary page before it */
 #define PQD_ERR_THRIFT (-12)               /* page header could not be parsed */
+#define PQD_ERR_REFUSED (-13)              /* malformed input that the reference decodes into padded or reinterpreted values and
+                                              this build refuses: a BYTE_ARRAY value running past the end of its page (the
+                                              reference zero pads it, encodingread.go:98-125), a value of 16 MiB or more,
+                                              v2 level sections that contradict the column's maximum levels (the reference
+                                              reads the next section in their place, layout/page.go:736-773) */
 
 /* parquet.Type (parquet/parquet.go:28-37) */
 enum { PQD_BOOLEAN = 0, PQD_INT32 = 1, PQD_INT64 = 2, PQD_INT96 = 3, PQD_FLOAT = 4, PQD_DOUBLE = 5,

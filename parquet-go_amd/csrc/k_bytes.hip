@@ -24,7 +24,7 @@ __device__ __forceinline__ uint64_t make_pair(int64_t src, int64_t len) { return
 // (pairs -> pairs_out[i]).
 // Reference semantics (encodingread.go:98-112): the 4-byte length is read leniently (zero filled when cut),
 // io.EOF only when a value starts exactly at the end.  A string that runs past the page would be zero
-// padded by the reference; here it fails the page as malformed.
+// padded by the reference; here the page is refused (PQD_ERR_REFUSED).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
   int p;
@@ -58,7 +58,7 @@ __global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
     for (int k = 0; k < 4; k++)
       if (pos + k < end) ln |= (uint32_t)c.in[pos + k] << (8 * k);
     pos = pos + 4 < end ? pos + 4 : end;
-    if ((int64_t)ln > end - pos || ln > (uint32_t)kMaxStrLen) { status = PQD_ERR_MALFORMED; break; }
+    if ((int64_t)ln > end - pos || ln > (uint32_t)kMaxStrLen) { status = PQD_ERR_REFUSED; break; }
     out[i] = make_pair(pos, ln);
     pos += ln;
   }
@@ -73,7 +73,7 @@ __global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
 __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *lens, uint64_t *pairs_out) {
   __shared__ int64_t s_scan[256];
   __shared__ int64_t s_carry;
-  __shared__ int s_bad;
+  __shared__ int s_bad, s_refused;
   const int d = blockIdx.x, tid = threadIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != encoding) return;
@@ -81,12 +81,13 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t cnt = ps->cnt, base = ps->dense_base;
   const int64_t end = ps->val_off + ps->val_len;
-  if (tid == 0) { s_carry = ps->aux0; s_bad = 0; }
+  if (tid == 0) { s_carry = ps->aux0; s_bad = 0; s_refused = 0; }
   __syncthreads();
   for (int64_t i0 = 0; i0 < cnt; i0 += 256) {
     const int64_t i = i0 + tid;
     int64_t ln = i < cnt ? lens[base + i] : 0;
-    if (ln < 0 || ln > kMaxStrLen) { s_bad = 1; ln = 0; }  // negative: make([]byte, huge) panics in the reference
+    if (ln < 0) { s_bad = 1; ln = 0; }  // make([]byte, huge) panics in the reference
+    if (ln > kMaxStrLen) { s_refused = 1; ln = 0; }
     s_scan[tid] = ln;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
     }
     const int64_t src = s_carry + s_scan[tid] - ln;
     if (i < cnt) {
-      if (ln > 0 && src + ln > end) s_bad = 1;  // the reference would zero pad a cut string (or hit EOF)
+      if (ln > 0 && src + ln > end) s_refused = 1;  // the reference would zero pad a cut string (or hit EOF at the next one)
       pairs_out[base + i] = make_pair(src, ln);
     }
     __syncthreads();
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
     __syncthreads();
   }
   if (tid == 0) {
-    if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
+    if (s_refused) set_status_b(&ps->status, PQD_ERR_REFUSED);
+    else if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
     ps->aux1 = s_carry;  // end of the payload
   }
 }
@@ -606,6 +608,26 @@ hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_ou
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, encoding, lens, pairs_out);
+  return hipGetLastError();
+}
+
+// Values of pages that have failed by now get length 0: their length words may hold anything, and the chunk-wide
+// offsets (and the size of the byte output) are sums over all of them.
+__global__ __launch_bounds__(256) void k_void_failed_pages(ChunkCtx c, uint64_t *pairs, int64_t *prefix) {
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  const PageState *ps = &c.state[p];
+  if (ps->status == 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  for (int i = threadIdx.x; i < ps->cnt; i += 256) {
+    pairs[base + i] = 0;
+    if (prefix) prefix[base + i] = 0;
+  }
+}
+
+hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_void_failed_pages, dim3(c.nd), dim3(256), 0, stream, c, pairs, prefix);
   return hipGetLastError();
 }
 

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   const uint64_t block_size = hdr[0], n_mb = hdr[1], n_values = hdr[2];
   const T first = DeltaTraits<T>::zigzag(hdr[3]);
   if (n_mb == 0) status = PQD_ERR_MALFORMED;                       // division by zero
-  else if (n_values < (uint64_t)cnt) status = PQD_ERR_MALFORMED;   // values[j] past the decoded count
-  else if (n_values >> 31) status = PQD_ERR_MALFORMED;
+  else if (n_values > (1ull << 30)) status = PQD_ERR_MALFORMED;    // stands for the reference running out of memory
+  else if (n_mb > 65535) status = PQD_ERR_MALFORMED;               // likewise (one uint64 per miniblock width)
   if (status != PQD_OK) {
     if (lane == 0) atomicCAS(&ps->status, 0, status);
     return;
@@ -328,8 +328,9 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
     }
   } else {
     // ---- any other geometry: straight from memory, one miniblock at a time ----
-    if (groups == 0 && n_values > 1) status = PQD_ERR_MALFORMED;  // the reference would loop forever
-    if (n_mb > 65535) status = PQD_ERR_MALFORMED;
+    // Miniblocks of fewer than 8 values hold nothing (ReadBitPacked is asked for zero groups): the reference reads
+    // block header after block header without ever gaining a value, until ReadByte meets the end of the stream.
+    if (groups == 0 && n_values > 1) status = PQD_ERR_EOF;
     const uint64_t vpm = groups * 8;
     while (status == PQD_OK && produced < n_values) {
       uint64_t md = 0;
@@ -370,6 +371,9 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
       }
     }
   }
+  // the caller slices the decoded values to the page's count (layout/page.go:917 values[j]): too few is an index out
+  // of range there, after the stream itself has been read without error
+  if (status == PQD_OK && n_values < (uint64_t)cnt) status = PQD_ERR_MALFORMED;
   if (lane == 0) {
     if (status != PQD_OK) atomicCAS(&ps->status, 0, status);
     ps->aux0 = src_off + (int64_t)(q - a);  // where the delta stream ended (start of a byte-array payload)

@@ -85,15 +85,17 @@ __global__ void k_page_setup(ChunkCtx c) {
       if (rll < 0 || dll < 0 || rll + dll > pi.body_len) {
         status = PQD_ERR_MALFORMED;
       } else {
+        // The reference re-frames a non-empty section with a synthetic length prefix and then reads prefixed blocks
+        // only for the levels the column has (layout/page.go:760-773, :835-881): a section that is empty although
+        // the column has that level, or present although it has not, makes it read the next section (or the values)
+        // in its place.  That reinterpretation is not reproduced: the page is refused.
+        if ((c.max_rep > 0) != (rll > 0)) status = PQD_ERR_REFUSED;
         if (c.max_rep > 0) {
-          // the reference re-frames the section with a synthetic length prefix only when it is non-empty
-          // (layout/page.go:760-764); an empty one with levels expected is malformed
-          if (rll == 0) status = PQD_ERR_MALFORMED;
           rs.off = pos; rs.len = (int32_t)rll; rs.avail = (int32_t)rll;
           rs.w = bit_len32((uint32_t)c.max_rep); rs.cnt = (int32_t)nv;
         }
+        if ((c.max_def > 0) != (dll > 0)) def_status = PQD_ERR_REFUSED;
         if (c.max_def > 0) {
-          if (dll == 0) def_status = PQD_ERR_MALFORMED;
           ds.off = pos + rll; ds.len = (int32_t)dll; ds.avail = (int32_t)dll;
           ds.w = bit_len32((uint32_t)c.max_def); ds.cnt = (int32_t)nv;
         }
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
     // the stream, while values are still wanted.  Branch-free apart from the rare exits; everything is
     // wave-uniform and stays on the scalar unit.  Anything else falls through to the general loop below.
     if (w > 0) {
-      const uint32_t lim = (qend - 12u < wq + (uint32_t)kWin && qend >= 12u) ? qend - 12u : (qend >= 12u ? wq + (uint32_t)kWin : 0u);
+      uint32_t lim = (qend - 12u < wq + (uint32_t)kWin && qend >= 12u) ? qend - 12u : (qend >= 12u ? wq + (uint32_t)kWin : 0u);
+      if (lim > q_avail_end) lim = q_avail_end;  // headers inside the zero fill of a short stream go the general way
       const uint32_t rle_mask = nb_rle >= 4 ? 0xFFFFFFFFu : ((1u << (8u * nb_rle)) - 1u);
       uint32_t o32 = out < (uint64_t)ucnt ? (uint32_t)out : ucnt;
       // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
@@ -267,6 +270,15 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
     }
 
     while (q - wq < (uint32_t)kWin && q < qend) {
+      if (q >= q_avail_end) {
+        // Everything from here to the end of the stream is the zero fill of a short Read (a length prefix larger
+        // than the page): headers of value 0, i.e. empty RLE runs of 1 + nb_rle bytes each.  Nothing more is
+        // decoded; the walk ends cleanly unless the last header sits on the last byte, where ReadRLE's Read of the
+        // value finds the buffer exhausted (encodingread.go:152-156).  Closed form instead of up to 2^30 steps.
+        if (nb_rle > 0 && (qend - q) % (1u + nb_rle) == 1u) status = PQD_ERR_EOF;
+        q = qend;
+        break;
+      }
       // 8 bytes at q, wave-uniform, on the scalar unit
       const uint32_t run_q = q;
       uint32_t di = (q - wq) >> 2;
@@ -327,8 +339,10 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
           q = qh + have;
         }
         e_x = 0; e_y = val;
+        if (out + nv > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }  // as for bit-packed runs below
       } else {  // bit-packed run, encodingread.go:170-228
-        if (c_or_g >> 27) { status = PQD_ERR_MALFORMED; break; }
+        // more than 2^30 values held at once stands for the reference running out of memory (16 bytes per boxed value)
+        if (c_or_g > (1u << 27) || out + 8ull * c_or_g > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }
         nv = c_or_g * 8u;
         q = qh;
         if (nv == 0) continue;

@@ -273,6 +273,13 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
             continue;
           }
         }
+        if (q >= q_avail_end) {
+          // the rest of the stream is the zero fill of a short Read: empty RLE runs of 1 + nb_rle bytes; the walk ends
+          // cleanly unless the last header sits on the last byte (encodingread.go:152-156: Read at the end -> io.EOF)
+          if (nb_rle > 0 && (qend - q) % (1u + nb_rle) == 1u) status = PQD_ERR_EOF;
+          q = qend;
+          break;
+        }
         // ---- one run the long way (encodingread.go:127-228) ----
         const uint32_t run_q = q;
         uint32_t di = (q - wq) >> 2;
@@ -329,8 +336,10 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
             q = qh + have;
           }
           e_x = 0; e_y = val;
+          if (out + nv > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }  // as for bit-packed runs below
         } else {  // bit-packed run, encodingread.go:170-228
-          if (c_or_g >> 27) { status = PQD_ERR_MALFORMED; break; }
+          // more than 2^30 values held at once stands for the reference running out of memory (16 bytes per boxed value)
+          if (c_or_g > (1u << 27) || out + 8ull * c_or_g > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }
           nv = c_or_g * 8u;
           q = qh;
           if (nv == 0) continue;

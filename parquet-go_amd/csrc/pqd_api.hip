@@ -462,6 +462,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int64_t n_dense = static_cast<const int64_t *>(h->host_small.p)[1];
     int64_t *doff = static_cast<int64_t *>(nullable ? h->doff.p : h->offsets.p);
+    HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
     { Prof pf(h, "k_len_offsets");
       HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, n_dense, static_cast<int64_t *>(h->scratch.p), doff, h->stream)); }
     HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->host_small.p) + 128, doff + n_dense, 8, hipMemcpyDeviceToHost, h->stream));
@@ -567,6 +568,7 @@ const char *pqd_strerror(int code) {
     case PQD_ERR_NOMEM: return "out of memory";
     case PQD_ERR_NO_DICTIONARY: return "dictionary-encoded page without a dictionary page";
     case PQD_ERR_THRIFT: return "page header could not be parsed";
+    case PQD_ERR_REFUSED: return "malformed input the reference pads or reinterprets; refused";
     default: return "unknown error";
   }
 }

@@ -49,6 +49,7 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
 // ---- k_bytes.hip ----
 hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_out, hipStream_t stream);
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream);
+hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream);
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
                               hipStream_t stream);
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
