@@ -165,6 +165,25 @@ __device__ __forceinline__ void win_store(const WinRegs &r, uint4 *win, int lane
   }
 }
 
+namespace {
+__device__ __forceinline__ uint32_t dpp_shr32(uint32_t x, int n) {
+  switch (n) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  }
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_sum32(uint32_t x) {
+#pragma unroll
+  for (int n = 1; n <= 8; n <<= 1) x += dpp_shr32(x, n);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return x;
+}
+}  // namespace
+
 __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   __shared__ uint4 win4[kWinVec];
   const uint32_t *win = reinterpret_cast<const uint32_t *>(win4);
@@ -206,6 +225,8 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   uint32_t ex = 0, ey = 0, ez = 0; // this lane's pending run entry
   uint32_t items = 0;              // work items of the runs emitted so far
   int status = PQD_OK;
+  int streak = 0;                  // one-byte-header RLE runs seen in a row
+  constexpr int kDenseAfter = 8;   // that many make the walk try whole strides of them at once
 
   // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
   // [wq, wq + kWin).  The next window is in flight (registers) while the current one is walked.
@@ -229,6 +250,55 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
       uint32_t o32 = out < (uint64_t)ucnt ? (uint32_t)out : ucnt;
       // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
       while (q < lim && o32 < ucnt) {
+        if (streak >= kDenseAfter) {
+          // Dense stretch (the reference's own writer emits nothing else, encodingwrite.go:149-214: one RLE run per
+          // change of value, a one-byte header and the value): as long as every run is of that shape the headers
+          // sit at a fixed stride, so every lane checks the header one stride further on and the leading lanes
+          // whose headers all have the shape are taken at once - up to 64 runs per step instead of one.
+          const int slot0 = nr & 63;                 // pending entries sit in lanes [0, slot0)
+          const int i = lane - slot0;
+          const uint32_t stride = 1u + nb_rle;
+          const uint32_t qi = q + (uint32_t)(i < 0 ? 0 : i) * stride;
+          bool ok = i >= 0 && qi < lim;
+          uint32_t hb = 0, vi = 0;
+          if (ok) {
+            const uint32_t dj = (qi - wq) >> 2, sj = (qi & 3u) * 8u;
+            const uint64_t x = ((((uint64_t)win[dj + 1]) << 32) | win[dj]) >> sj;   // header and up to four value bytes
+            hb = (uint32_t)x & 0xFFu;
+            vi = (uint32_t)(x >> 8) & rle_mask;
+            ok = (hb & 0x81u) == 0u && hb != 0u;     // one byte, RLE, not empty
+          }
+          const uint64_t okm = __ballot(ok) >> slot0;
+          int n_ok = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);
+          if (n_ok > 64 - slot0) n_ok = 64 - slot0;
+          if (n_ok >= 2) {
+            const uint32_t nvi = (i >= 0 && i < n_ok) ? hb >> 1 : 0u;
+            const uint32_t incl_v = wave_incl_sum32(nvi);
+            const uint64_t full = __ballot(i >= 0 && i < n_ok && incl_v >= ucnt - o32);   // the run that completes the count
+            const int n_take = full ? (int)__builtin_ctzll(full) - slot0 + 1 : n_ok;
+            const bool mine = i >= 0 && i < n_take;
+            const uint32_t iti = mine ? (nvi + 7u) >> 3 : 0u;
+            const uint32_t incl_i = wave_incl_sum32(iti);
+            if (mine) {
+              const uint32_t start = o32 + incl_v - nvi;
+              ex = start; ey = vi; ez = items + incl_i - iti;
+              const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
+              const uint32_t kt = (start + kTile - 1) & ~(uint32_t)(kTile - 1);
+              if (kt < endc) tile_run[kt / kTile] = make_int2(nr + i, (int)(qi - a));   // a run of < 64 values meets at most one tile start
+            }
+            const int last = slot0 + n_take - 1;
+            o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, last);
+            items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, last);
+            nr += n_take;
+            q += (uint32_t)n_take * stride;
+            if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+            emit_end = o32;
+            emit_q = q;
+            if (n_take < 8) streak = 0;
+            continue;
+          }
+          streak = 0;
+        }
         const uint32_t run_q = q;
         const uint32_t di = (q - wq) >> 2;
         const uint32_t sh = (q & 3u) * 8u;
@@ -252,6 +322,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
         const uint32_t nq = q + hlen + nbytes;
         q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
         if (__builtin_expect(nv == 0, 0)) continue;
+        streak = (isbp | two) ? 0 : streak + 1;
         const uint32_t endv = o32 + nv;
         const uint32_t endc = endv < ucnt ? endv : ucnt;
         const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);

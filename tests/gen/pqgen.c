@@ -43,18 +43,20 @@ static inline void pk_put(packer *k, uint64_t v, int w) {
   while (k->bits >= 8) { *k->p++ = (uint8_t)k->acc; k->acc >>= 8; k->bits -= 8; }
 }
 
-int64_t pqgen_dict_slot_bytes(int64_t page_values, int w) {
+int64_t pqgen_dict_slot_bytes2(int64_t page_values, int w, int style) {
   int64_t b = page_values * (int64_t)(w ? w : 1) / 8 + page_values / 2 + 256;
   if (w == 32) b = page_values * 5 + 256;  /* parquet-go-like worst case: one 5-byte run per value */
+  if (style == 1 && b < page_values * (1 + (w + 7) / 8) + 256) b = page_values * (1 + (w + 7) / 8) + 256;
   return (b + 255) / 256 * 256;
 }
+int64_t pqgen_dict_slot_bytes(int64_t page_values, int w) { return pqgen_dict_slot_bytes2(page_values, w, 0); }
 
 /* Returns the number of pages (dictionary page first) or -1 if the buffer is too small.
  * style 0 = arrow-like mix, 1 = parquet-go-like (RLE runs only; repeats: each index is repeated U[1,rep_max] times) */
 int32_t pqgen_dict_chunk(uint64_t seed, int64_t n_values, int w, int32_t dict_n, int64_t page_values, int style,
                          int rep_max, uint8_t *buf, int64_t cap, page_desc *pages, int32_t page_cap) {
   const int64_t n_pages = (n_values + page_values - 1) / page_values;
-  const int64_t slot = pqgen_dict_slot_bytes(page_values, w);
+  const int64_t slot = pqgen_dict_slot_bytes2(page_values, w, style);
   const int64_t dict_bytes = ((int64_t)dict_n * 4 + 255) / 256 * 256;
   if (n_pages + 1 > page_cap || dict_bytes + n_pages * slot > cap) return -1;
   /* dictionary: random int32 */

@@ -30,6 +30,8 @@ def lib():
         L = C.CDLL(so)
         L.pqgen_dict_slot_bytes.restype = C.c_int64
         L.pqgen_dict_slot_bytes.argtypes = [C.c_int64, C.c_int]
+        L.pqgen_dict_slot_bytes2.restype = C.c_int64
+        L.pqgen_dict_slot_bytes2.argtypes = [C.c_int64, C.c_int, C.c_int]
         L.pqgen_delta_slot_bytes.restype = C.c_int64
         L.pqgen_delta_slot_bytes.argtypes = [C.c_int64, C.c_int]
         L.pqgen_dict_chunk.restype = C.c_int32
@@ -53,7 +55,7 @@ def lib():
 def dict_chunk(seed, n_values, w, dict_n, page_values, style=0, rep_max=4, out=None):
     """-> (chunk uint8 array, page descriptors).  RLE_DICTIONARY INT32 chunk: dictionary page + v1 data pages."""
     n_pages = (n_values + page_values - 1) // page_values
-    cap = (dict_n * 4 + 255) // 256 * 256 + n_pages * lib().pqgen_dict_slot_bytes(page_values, w) + 64
+    cap = (dict_n * 4 + 255) // 256 * 256 + n_pages * lib().pqgen_dict_slot_bytes2(page_values, w, style) + 64
     buf = out if out is not None else np.zeros(cap, np.uint8)
     assert buf.size >= cap
     pages = np.zeros(n_pages + 1, PAGE_DESC_DTYPE)

@@ -138,6 +138,57 @@ def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
     check_same(dec, oracle, chunk, pages, pg.INT32)
 
 
+@pytest.mark.parametrize("variant", ["wave", "wide"])
+@pytest.mark.parametrize("w", [1, 2, 7, 8, 9, 16, 20, 32])
+def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant, monkeypatch):
+    # long stretches of one-byte-header RLE runs (what WriteRLE emits, encodingwrite.go:149-172) broken up by runs of
+    # 64 or more values (two-byte header), bit-packed runs and empty runs; pages whose count ends inside a stretch,
+    # stretches that cross tile and window boundaries; levels written the same way
+    monkeypatch.setenv("PQD_PRESCAN", variant)
+    rng = np.random.default_rng(900 + w)
+    nd = min(1 << w, 5000)
+
+    def dense_runs(n_target):
+        out, vals = bytearray(), []
+        nb = (w + 7) // 8
+        while len(vals) < n_target:
+            kind = rng.integers(0, 200)
+            if kind == 0:      # two-byte header
+                c, v = int(rng.integers(64, 400)), int(rng.integers(0, nd))
+                out += pg.varint(c << 1) + v.to_bytes(4, "little")[:nb]
+                vals += [v] * c
+            elif kind == 1:    # bit-packed groups
+                g = int(rng.integers(1, 4))
+                x = rng.integers(0, nd, 8 * g)
+                out += pg.varint((g << 1) | 1) + pg.bitpack(x, w)
+                vals += [int(t) for t in x]
+            elif kind == 2:    # empty run
+                out += b"\x00" + bytes(nb)
+            else:
+                c, v = int(rng.integers(1, 64 if kind % 3 else 3)), int(rng.integers(0, nd))
+                out += bytes([c << 1]) + v.to_bytes(4, "little")[:nb]
+                vals += [v] * c
+        return bytes(out), vals
+
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 7)), lead=int(rng.integers(0, 3)))
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    for n_target in (50, 4096, 9000, 40000):
+        body, vals = dense_runs(n_target)
+        n = len(vals) - int(rng.integers(0, min(40, len(vals))))   # the page's count may end inside a run or a stretch
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([w]) + body)
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32)
+    # levels as the reference writes them: RLE runs only
+    cb = pg.ChunkBuilder(gap=1)
+    for n in (300, 20000):
+        dl, rl = _levels(rng, n, 3, 2)
+        nn = int((dl == 3).sum())
+        cb.data_page_v1(pg.ENC_PLAIN, n, rng.integers(-2**31, 2**31, nn, dtype=np.int64).astype(np.int32).tobytes(),
+                        pg.level_block_v1(rl, 2, rng, "rle"), pg.level_block_v1(dl, 3, rng, "rle"))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT32, 0, 3, 2)
+
+
 @pytest.mark.parametrize("ptype,tl", [(pg.INT32, 0), (pg.INT64, 0), (pg.FLOAT, 0), (pg.DOUBLE, 0), (pg.INT96, 0),
                                       (pg.FIXED_LEN_BYTE_ARRAY, 7), (pg.BOOLEAN, 0)])
 def test_plain_fixed(dec, oracle, ptype, tl):
