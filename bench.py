@@ -328,6 +328,20 @@ def run_extras(args, dec, local_rank):
                 best, kt = dt, dec.kernel_times()
         return best, kt, r
 
+    # configs[0]-shaped: what the reference's own writer produces (layout/dictpage.go:155-158, encodingwrite.go:183-214):
+    # dictionary indices at width 32 as RLE runs only, one run per change of value, pages of about 8 KiB
+    try:
+        n = 64 << 20
+        chunk, pages = pqgen.dict_chunk(0x5EED0007, n, 32, 4096, 2048, 1, 2)
+        best, kt, r = timed_device(chunk, pages, pq.INT32)
+        extra["parquet_go_written"] = {"workload": "INT32 dictionary chunk as parquet-go writes it: width-32 RLE runs only (1-2 values per "
+                                                   "run), %d Mi values in %d pages of 2048 values" % (n >> 20, len(pages) - 1),
+                                       "decoded_GBps": round(n * 4 / best / 1e9, 1), "ms": round(best * 1e3, 3),
+                                       "in_bytes": int(pages["length"].sum()),
+                                       "kernel_ms": {k_: round(v[0], 3) for k_, v in kt.items()}}
+    except Exception as e:
+        extra["parquet_go_written"] = {"error": repr(e)}
+
     # configs[4]: nested levels (optional list of optional int64), PLAIN values
     try:
         n = args.list_slots

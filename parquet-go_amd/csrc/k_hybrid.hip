@@ -467,91 +467,108 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pages_finalize: one block.  After the levels are expanded: per-page null / row / value counts
-// (layout/page.go:883-888, :925-927), running bases, and the descriptor of the value section
-// (dictionary pages: first byte is the index width, the rest is the hybrid stream, layout/page.go:644-655).
+// After the levels are expanded: per-page null / row / value counts (layout/page.go:883-888, :925-927), running
+// bases, and the descriptor of the value section (dictionary pages: first byte is the index width, the rest is the
+// hybrid stream, layout/page.go:644-655).  Three steps, so that a chunk of tens of thousands of small pages (the
+// reference's writer cuts pages at 8 KiB) is not walked by a single workgroup: counts per page (one thread per
+// page), one workgroup scanning the counts, value streams per page.
 // totals: [0] slots [1] values [2] nulls [3] rows
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pages_count(ChunkCtx c) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= c.n_pages) return;
+  const PageIn pi = c.pages[p];
+  if (pi.data_idx < 0) return;
+  PageState *ps = &c.state[p];
+  // a failed level stream fails the page
+  int st = ps->status;
+  if (st == 0 && c.max_rep > 0) st = c.streams[pi.data_idx].status;
+  if (st == 0 && c.max_def > 0) st = c.streams[c.nd + pi.data_idx].status;
+  const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
+  const int64_t nulls = c.max_def > 0 ? ps->n_nulls : 0;
+  const int64_t rows = c.max_rep > 0 ? ps->n_rows : nv;
+  ps->status = st;
+  ps->n_nulls = (int32_t)nulls;
+  ps->n_rows = (int32_t)rows;
+  ps->cnt = st != 0 ? 0 : (int32_t)(nv - nulls);
+}
+
 __global__ __launch_bounds__(1024) void k_pages_finalize(ChunkCtx c, int64_t *totals) {
-  __shared__ int64_t s_part[1024];
-  __shared__ int64_t s_carry[4];
-  const int tid = threadIdx.x;
-  if (tid < 4) s_carry[tid] = 0;
+  constexpr int kPer = 4;                       // consecutive pages per thread and round: their loads overlap
+  __shared__ int64_t s_wave[16];
+  __shared__ unsigned long long s_tot[4];       // running totals: slots, values, nulls, rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 4) s_tot[tid] = 0;
   __syncthreads();
-  for (int p0 = 0; p0 < c.n_pages; p0 += 1024) {
-    const int p = p0 + tid;
-    int64_t cnt = 0, nv = 0, nulls = 0, rows = 0;
-    PageIn pi;
-    if (p < c.n_pages) {
-      pi = c.pages[p];
-      if (pi.data_idx >= 0) {
-        PageState *ps = &c.state[p];
-        // a failed level stream fails the page
-        int st = ps->status;
-        if (st == 0 && c.max_rep > 0) st = c.streams[pi.data_idx].status;
-        if (st == 0 && c.max_def > 0) st = c.streams[c.nd + pi.data_idx].status;
-        nv = pi.num_values > 0 ? pi.num_values : 0;
-        nulls = c.max_def > 0 ? ps->n_nulls : 0;
-        rows = c.max_rep > 0 ? ps->n_rows : nv;
-        cnt = nv - nulls;
-        if (st != 0) { cnt = 0; }
-        ps->status = st;
-        ps->n_nulls = (int32_t)nulls;
-        ps->n_rows = (int32_t)rows;
-        ps->cnt = (int32_t)cnt;
+  for (int p0 = 0; p0 < c.n_pages; p0 += 1024 * kPer) {
+    const int64_t carry_cnt = (int64_t)s_tot[1];  // values of the pages before this round
+    int64_t cnt[kPer], sum[4] = {0, 0, 0, 0};
+    bool data[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int p = p0 + tid * kPer + j;
+      cnt[j] = 0;
+      data[j] = p < c.n_pages && c.pages[p].data_idx >= 0;
+      if (data[j]) {
+        const int64_t nv = c.pages[p].num_values > 0 ? c.pages[p].num_values : 0;
+        const PageState *ps = &c.state[p];
+        cnt[j] = ps->cnt;
+        sum[0] += nv; sum[1] += cnt[j]; sum[2] += ps->n_nulls; sum[3] += ps->n_rows;
       }
     }
-    // block exclusive scan of cnt
-    s_part[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      int64_t t = tid >= o ? s_part[tid - o] : 0;
-      __syncthreads();
-      s_part[tid] += t;
-      __syncthreads();
-    }
-    const int64_t incl = s_part[tid];
-    const int64_t base = s_carry[1] + incl - cnt;
-    if (p < c.n_pages && pi.data_idx >= 0) {
-      PageState *ps = &c.state[p];
-      ps->dense_base = base;
-      Stream *vs = &c.streams[2 * c.nd + pi.data_idx];
-      vs->out_base = base;
-      vs->cnt = 0;
-      vs->status = ps->status;
-      const bool dict_enc = pi.encoding == PQD_ENC_PLAIN_DICTIONARY || pi.encoding == PQD_ENC_RLE_DICTIONARY;
-      if (ps->status == 0 && cnt > 0 && dict_enc) {
-        int64_t off = ps->val_off, len = ps->val_len;
-        int st = 0;
-        if (len <= 0) st = PQD_ERR_EOF;        // ReadByte at the end
-        else if (len == 1) st = PQD_ERR_EOF;   // no run bytes: the reference then looks for a length prefix and hits EOF
-        if (st == 0) {
-          vs->w = c.in[off];
-          vs->off = off + 1;
-          vs->len = (int32_t)(len - 1);
-          vs->avail = (int32_t)(len - 1);
-          vs->cnt = (int32_t)cnt;
-        } else {
-          ps->status = st;
-          vs->status = st;
-        }
-      }
-    }
-    __syncthreads();
-    // carries: totals of this group of pages
-    int64_t vals[4] = {nv, cnt, nulls, rows};
+    // exclusive scan of the threads' value counts: inside the wave by shuffles, across the 16 waves through LDS
+    int64_t x = sum[1];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();   // every thread has read its carry from s_tot by now
+#pragma unroll
     for (int q = 0; q < 4; q++) {
-      s_part[tid] = vals[q];
-      __syncthreads();
-      for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) s_part[tid] += s_part[tid + o];
-        __syncthreads();
-      }
-      if (tid == 0) s_carry[q] += s_part[0];
-      __syncthreads();
+      int64_t t = sum[q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+      if (lane == 0 && t != 0) atomicAdd(&s_tot[q], (unsigned long long)t);   // read again after the barrier that ends the round
+    }
+    int64_t base = carry_cnt + x - sum[1];
+    for (int k = 0; k < wave; k++) base += s_wave[k];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      if (data[j]) c.state[p0 + tid * kPer + j].dense_base = base;
+      base += cnt[j];
+    }
+    __syncthreads();   // s_wave and the read of s_tot[1] at the top of the next round
+  }
+  if (tid < 4) totals[tid] = (int64_t)s_tot[tid];
+}
+
+__global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= c.n_pages) return;
+  const PageIn pi = c.pages[p];
+  if (pi.data_idx < 0) return;
+  PageState *ps = &c.state[p];
+  Stream *vs = &c.streams[2 * c.nd + pi.data_idx];
+  const int64_t cnt = ps->cnt;
+  vs->out_base = ps->dense_base;
+  vs->cnt = 0;
+  vs->status = ps->status;
+  const bool dict_enc = pi.encoding == PQD_ENC_PLAIN_DICTIONARY || pi.encoding == PQD_ENC_RLE_DICTIONARY;
+  if (ps->status == 0 && cnt > 0 && dict_enc) {
+    const int64_t off = ps->val_off, len = ps->val_len;
+    int st = 0;
+    if (len <= 0) st = PQD_ERR_EOF;        // ReadByte at the end
+    else if (len == 1) st = PQD_ERR_EOF;   // no run bytes: the reference then looks for a length prefix and hits EOF
+    if (st == 0) {
+      vs->w = c.in[off];
+      vs->off = off + 1;
+      vs->len = (int32_t)(len - 1);
+      vs->avail = (int32_t)(len - 1);
+      vs->cnt = (int32_t)cnt;
+    } else {
+      ps->status = st;
+      vs->status = st;
     }
   }
-  if (tid < 4) totals[tid] = s_carry[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,13 +608,36 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, hi
   return hipGetLastError();
 }
 
+// the same over many workgroups, for chunks of many pages: out[1] starts as a large sentinel (0x7F7F7F7F)
+__global__ __launch_bounds__(256) void k_collect_status_wide(ChunkCtx c, int32_t *out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= c.n_pages) return;
+  int st = c.state[p].status;
+  const int d = c.pages[p].data_idx;
+  if (st == 0 && d >= 0) st = c.streams[2 * c.nd + d].status;
+  if (st != 0) { atomicMin(&out[1], p); c.state[p].status = st; }
+}
+__global__ void k_collect_status_done(ChunkCtx c, int32_t *out) {
+  if (out[1] == 0x7F7F7F7F) { out[0] = 0; out[1] = -1; }
+  else out[0] = c.state[out[1]].status;
+}
+
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(1024), 0, stream, c, out);
+  if (c.n_pages <= 4096) {
+    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(1024), 0, stream, c, out);
+  } else {
+    hipError_t e = hipMemsetAsync(out + 1, 0x7F, 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_collect_status_wide, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c, out);
+    hipLaunchKernelGGL(k_collect_status_done, dim3(1), dim3(1), 0, stream, c, out);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream) {
+  if (c.n_pages > 0) hipLaunchKernelGGL(k_pages_count, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c);
   hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(1024), 0, stream, c, totals);
+  if (c.n_pages > 0) hipLaunchKernelGGL(k_pages_values, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c);
   return hipGetLastError();
 }
 
