@@ -225,8 +225,8 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   uint32_t ex = 0, ey = 0, ez = 0; // this lane's pending run entry
   uint32_t items = 0;              // work items of the runs emitted so far
   int status = PQD_OK;
-  int streak = 0;                  // one-byte-header RLE runs seen in a row
-  constexpr int kDenseAfter = 8;   // that many make the walk try whole strides of them at once
+  bool dense = false;              // most of the last 64 runs were one-byte-header RLE runs: try whole strides of them at once
+  uint32_t rg = 0;                 // this lane's pending entry is such a run
 
   // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
   // [wq, wq + kWin).  The next window is in flight (registers) while the current one is walked.
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
       uint32_t o32 = out < (uint64_t)ucnt ? (uint32_t)out : ucnt;
       // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
       while (q < lim && o32 < ucnt) {
-        if (streak >= kDenseAfter) {
+        if (dense) {
           // Dense stretch (the reference's own writer emits nothing else, encodingwrite.go:149-214: one RLE run per
           // change of value, a one-byte header and the value): as long as every run is of that shape the headers
           // sit at a fixed stride, so every lane checks the header one stride further on and the leading lanes
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
             const uint32_t incl_i = wave_incl_sum32(iti);
             if (mine) {
               const uint32_t start = o32 + incl_v - nvi;
-              ex = start; ey = vi; ez = items + incl_i - iti;
+              ex = start; ey = vi; ez = items + incl_i - iti; rg = 0xFFFFFFFFu;
               const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
               const uint32_t kt = (start + kTile - 1) & ~(uint32_t)(kTile - 1);
               if (kt < endc) tile_run[kt / kTile] = make_int2(nr + i, (int)(qi - a));   // a run of < 64 values meets at most one tile start
@@ -294,10 +294,10 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
             if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
             emit_end = o32;
             emit_q = q;
-            if (n_take < 8) streak = 0;
+            if (n_take < 8) dense = false;
             continue;
           }
-          streak = 0;
+          dense = false;
         }
         const uint32_t run_q = q;
         const uint32_t di = (q - wq) >> 2;
@@ -322,17 +322,19 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
         const uint32_t nq = q + hlen + nbytes;
         q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
         if (__builtin_expect(nv == 0, 0)) continue;
-        streak = (isbp | two) ? 0 : streak + 1;
         const uint32_t endv = o32 + nv;
         const uint32_t endc = endv < ucnt ? endv : ucnt;
         const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);
         if (__builtin_expect(kt < endc, 0))
           for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
             tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
-        if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; }
+        if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; rg = (isbp | two) - 1u; }
         nr++;
         items += (nv + 7u) >> 3;
-        if (__builtin_expect((nr & 63) == 0, 0)) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+        if (__builtin_expect((nr & 63) == 0, 0)) {
+          runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+          dense = __builtin_popcountll(__ballot(rg != 0u)) >= 48;  // most of these 64 runs: RLE with a one-byte header
+        }
         emit_end = endv;
         emit_q = q;
         o32 = endv;

@@ -146,8 +146,7 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
   uint64_t dec_mask = 0;           // bit i: pending record i already holds rx / ry (else they are read from the table
                                    // and the raw bytes before the window goes away)
   int status = PQD_OK;
-  int streak = 0;                  // one-byte-header RLE runs hopped over in a row
-  constexpr int kDenseAfter = 8;   // that many make the walk try whole strides of them at once
+  bool dense = false;              // most of the last 64 runs were one-byte-header RLE runs: try whole strides of them at once
   const uint32_t stride = 1u + nb_rle;
 
   // ---- builder state ----
@@ -198,6 +197,8 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
     }
     base_out += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, 63);
     base_items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, 63);
+    // an RLE run of fewer than 64 values has a one-byte header
+    if (pending == 64) dense = __builtin_popcountll(__ballot((rx >> 31) == 0u && nv < 64u)) >= 48;
     nr_flushed = nr;
     dec_mask = 0;
   };
@@ -255,13 +256,14 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
           uint32_t o32 = (uint32_t)out;
           int np = nr - nr_flushed;
           const int np0 = np;
-          for (;;) {
-            const uint32_t o = q - wq;
-            if (o >= (uint32_t)kWin) break;
-            if (streak >= kDenseAfter) {
-              // Dense stretch of one-byte-header RLE runs (all the reference's own writer emits,
-              // encodingwrite.go:149-214): their headers sit at a fixed stride, so every free lane looks up the
-              // position one stride further on and the leading lanes that all find such a run are noted at once.
+          if (dense) {
+            // Dense stretch of one-byte-header RLE runs (all the reference's own writer emits,
+            // encodingwrite.go:149-214): their headers sit at a fixed stride, so every free lane looks up the
+            // position one stride further on and the leading lanes that all find such a run are noted at once.
+            // (Kept apart from the hop loop below, whose few instructions per run are the kernel's critical path.)
+            for (;;) {
+              const uint32_t o = q - wq;
+              if (o >= (uint32_t)kWin) break;
               const int i = lane - np;
               const uint32_t oi = o + (uint32_t)(i < 0 ? 0 : i) * stride;
               bool ok = i >= 0 && oi < (uint32_t)kWin;
@@ -271,31 +273,32 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
               const uint64_t okm = __ballot(ok) >> np;
               int n_ok = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);
               if (n_ok > 64 - np) n_ok = 64 - np;
-              if (n_ok >= 2) {
-                const uint32_t nvi = (i >= 0 && i < n_ok) ? ti.y : 0u;
-                const uint32_t incl = wave_incl_sum(nvi);
-                const uint64_t full = __ballot(i >= 0 && i < n_ok && incl >= ucnt - o32);  // the run that completes the count
-                const int n_take = full ? (int)__builtin_ctzll(full) - np + 1 : n_ok;
-                if (i >= 0 && i < n_take) rq = wq + oi;
-                o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl, np + n_take - 1);
-                np += n_take;
-                q += (uint32_t)n_take * stride;
-                if (n_take < 8) streak = 0;
-                if (np == 64 || o32 >= ucnt) break;
-                continue;
-              }
-              streak = 0;
+              if (n_ok < 2) { dense = false; break; }
+              const uint32_t nvi = (i >= 0 && i < n_ok) ? ti.y : 0u;
+              const uint32_t incl = wave_incl_sum(nvi);
+              const uint64_t full = __ballot(i >= 0 && i < n_ok && incl >= ucnt - o32);  // the run that completes the count
+              const int n_take = full ? (int)__builtin_ctzll(full) - np + 1 : n_ok;
+              if (i >= 0 && i < n_take) rq = wq + oi;
+              o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl, np + n_take - 1);
+              np += n_take;
+              q += (uint32_t)n_take * stride;
+              if (n_take < 8) { dense = false; break; }
+              if (np == 64 || o32 >= ucnt) break;
             }
-            const uint2 te = sh.tab[b][o];
-            const uint32_t adv = __builtin_amdgcn_readfirstlane(te.x);
-            const uint32_t nvf = __builtin_amdgcn_readfirstlane(te.y);
-            if (adv == 0u) break;
-            rq = write_lane(rq, q, np);
-            np++;
-            o32 += nvf & 0x7FFFFFFFu;
-            q += adv;
-            streak = (adv == stride && (nvf >> 31) == 0u) ? streak + 1 : 0;
-            if (np == 64 || o32 >= ucnt) break;
+          } else {
+            for (;;) {
+              const uint32_t o = q - wq;
+              if (o >= (uint32_t)kWin) break;
+              const uint2 te = sh.tab[b][o];
+              const uint32_t adv = __builtin_amdgcn_readfirstlane(te.x);
+              const uint32_t nvf = __builtin_amdgcn_readfirstlane(te.y);
+              if (adv == 0u) break;
+              rq = write_lane(rq, q, np);
+              np++;
+              o32 += nvf & 0x7FFFFFFFu;
+              q += adv;
+              if (np == 64 || o32 >= ucnt) break;
+            }
           }
           if (np != np0) {
             nr = nr_flushed + np;
