@@ -43,7 +43,8 @@ extern "C" {
                                               this build refuses: a BYTE_ARRAY value running past the end of its page (the
                                               reference zero pads it, encodingread.go:98-125), a value of 16 MiB or more,
                                               v2 level sections that contradict the column's maximum levels (the reference
-                                              reads the next section in their place, layout/page.go:736-773) */
+                                              reads the next section in their place, layout/page.go:736-773), length or
+                                              prefix streams of byte-array pages announcing more values than the page holds */
 
 /* parquet.Type (parquet/parquet.go:28-37) */
 enum { PQD_BOOLEAN = 0, PQD_INT32 = 1, PQD_INT64 = 2, PQD_INT96 = 3, PQD_FLOAT = 4, PQD_DOUBLE = 5,

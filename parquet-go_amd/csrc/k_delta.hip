@@ -374,6 +374,10 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   // the caller slices the decoded values to the page's count (layout/page.go:917 values[j]): too few is an index out
   // of range there, after the stream itself has been read without error
   if (status == PQD_OK && n_values < (uint64_t)cnt) status = PQD_ERR_MALFORMED;
+  // Length and prefix streams of byte-array pages that announce more values than the page holds: the reference
+  // builds (and may fail on) every one of those strings (encodingread.go:394-406, :425-433); the strings beyond
+  // the page's count are not looked at here, so such a page is refused rather than decoded differently.
+  if (status == PQD_OK && encoding != PQD_ENC_DELTA_BINARY_PACKED && n_values > (uint64_t)cnt) status = PQD_ERR_REFUSED;
   if (lane == 0) {
     if (status != PQD_OK) atomicCAS(&ps->status, 0, status);
     ps->aux0 = src_off + (int64_t)(q - a);  // where the delta stream ended (start of a byte-array payload)

@@ -103,7 +103,8 @@ __global__ void k_page_setup(ChunkCtx c) {
       }
     }
   }
-  ps.status = status;
+  // (without definition levels there is no level stream to carry def_status to the page)
+  ps.status = status != PQD_OK ? status : (c.max_def > 0 ? PQD_OK : def_status);
   ps.val_off = pos;
   ps.val_len = end - pos;
   rs.status = status;
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
       // varint header (encodingread.go:127-143).  Bytes past the end of the stream read as zero, which ends
       // the varint with the partial value the reference returns at EOF.
       uint32_t header, hlen;
+      bool huge = false;  // a header of 2^31 or more: a run of at least 2^30 values
       if ((x0 & 0x80u) == 0) { header = x0 & 0x7Fu; hlen = 1; }
       else if ((x0 & 0x8000u) == 0) { header = (x0 & 0x7Fu) | ((x0 >> 1) & 0x3F80u); hlen = 2; }
       else {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
           if ((b & 0x80u) == 0) break;
           shift += 7;
         }
-        if (h64 >> 31) { status = PQD_ERR_MALFORMED; break; }  // a run of >= 2^30 values: the reference runs out of memory
+        huge = (h64 >> 31) != 0;  // the reference runs out of memory on it, after ReadRLE has read the value (encodingread.go:152-165)
         header = (uint32_t)h64;
         hlen = n;
         // the bytes after the header, for an RLE value
@@ -412,10 +414,10 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
           q = qh + have;
         }
         e_x = 0; e_y = val;
-        if (out + nv > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }  // as for bit-packed runs below
+        if (huge || out + nv > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }  // as for bit-packed runs below
       } else {  // bit-packed run, encodingread.go:170-228
         // more than 2^30 values held at once stands for the reference running out of memory (16 bytes per boxed value)
-        if (c_or_g > (1u << 27) || out + 8ull * c_or_g > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }
+        if (huge || c_or_g > (1u << 27) || out + 8ull * c_or_g > (1ull << 30)) { status = PQD_ERR_MALFORMED; break; }
         nv = c_or_g * 8u;
         q = qh;
         if (nv == 0) continue;
