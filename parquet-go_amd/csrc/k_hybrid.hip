@@ -227,7 +227,6 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   uint32_t items = 0;              // work items of the runs emitted so far
   int status = PQD_OK;
   bool dense = false;              // most of the last 64 runs were one-byte-header RLE runs: try whole strides of them at once
-  uint32_t rg = 0;                 // this lane's pending entry is such a run
 
   // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
   // [wq, wq + kWin).  The next window is in flight (registers) while the current one is walked.
@@ -250,15 +249,64 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
       const uint32_t rle_mask = nb_rle >= 4 ? 0xFFFFFFFFu : ((1u << (8u * nb_rle)) - 1u);
       uint32_t o32 = out < (uint64_t)ucnt ? (uint32_t)out : ucnt;
       // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
-      while (q < lim && o32 < ucnt) {
-        if (dense) {
-          // Dense stretch (the reference's own writer emits nothing else, encodingwrite.go:149-214: one RLE run per
-          // change of value, a one-byte header and the value): as long as every run is of that shape the headers
-          // sit at a fixed stride, so every lane checks the header one stride further on and the leading lanes
-          // whose headers all have the shape are taken at once - up to 64 runs per step instead of one.
+      for (;;) {
+        // one run at a time; the loop bound drops to 0 when the 64 runs of a flush say the stream is dense
+        uint32_t hot_lim = dense ? 0u : lim;
+        bool long_header = false;
+        while (q < hot_lim && o32 < ucnt) {
+          const uint32_t run_q = q;
+          const uint32_t di = (q - wq) >> 2;
+          const uint32_t sh = (q & 3u) * 8u;
+          const uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
+          const uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
+          const uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
+          const uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+          const uint32_t x1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+          const uint32_t two = (x0 >> 7) & 1u;
+          if (__builtin_expect((x0 & 0x8080u) == 0x8080u, 0)) { long_header = true; break; }  // header of 3 or more bytes
+          const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
+          const uint32_t hlen = 1u + two;
+          const uint32_t isbp = header & 1u;
+          const uint32_t cg = header >> 1;
+          const uint32_t nv = cg << (isbp * 3u);
+          const uint32_t nbytes = ((cg * (uint32_t)w) & (0u - isbp)) | (nb_rle & (isbp - 1u));
+          const uint32_t val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen)) & rle_mask;
+          const uint32_t bpm = 0u - isbp;  // all ones for a bit-packed run
+          const uint32_t e_y = ((q + hlen - a) & bpm) | (val & ~bpm);
+          const uint32_t e_x = (isbp << 31) | o32;
+          const uint32_t nq = q + hlen + nbytes;
+          q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
+          if (__builtin_expect(nv == 0, 0)) continue;
+          const uint32_t endv = o32 + nv;
+          const uint32_t endc = endv < ucnt ? endv : ucnt;
+          const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);
+          if (__builtin_expect(kt < endc, 0))
+            for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
+              tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
+          if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; }
+          nr++;
+          items += (nv + 7u) >> 3;
+          if (__builtin_expect((nr & 63) == 0, 0)) {
+            runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+            // how many of these 64 runs were RLE runs of fewer than 64 values (a one-byte header)?
+            const uint32_t nxt = (uint32_t)__shfl_down((int)(ex & 0x7FFFFFFFu), 1);
+            const uint32_t nvl = (lane == 63 ? endv : nxt) - (ex & 0x7FFFFFFFu);
+            dense = __builtin_popcountll(__ballot((ex >> 31) == 0u && nvl < 64u)) >= 48;
+            if (dense) hot_lim = 0u;
+          }
+          emit_end = endv;
+          emit_q = q;
+          o32 = endv;
+        }
+        if (!dense || long_header) break;
+        // Dense stretch (the reference's own writer emits nothing else, encodingwrite.go:149-214: one RLE run per
+        // change of value, a one-byte header and the value): as long as every run is of that shape the headers
+        // sit at a fixed stride, so every lane checks the header one stride further on and the leading lanes
+        // whose headers all have the shape are taken at once - up to 64 runs per step instead of one.
+        const uint32_t stride = 1u + nb_rle;
+        while (q < lim && o32 < ucnt) {
           const int slot0 = nr & 63;                 // pending entries sit in lanes [0, slot0)
           const int i = lane - slot0;
-          const uint32_t stride = 1u + nb_rle;
           const uint32_t qi = q + (uint32_t)(i < 0 ? 0 : i) * stride;
           bool ok = i >= 0 && qi < lim;
           uint32_t hb = 0, vi = 0;
@@ -272,73 +320,32 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
           const uint64_t okm = __ballot(ok) >> slot0;
           int n_ok = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);
           if (n_ok > 64 - slot0) n_ok = 64 - slot0;
-          if (n_ok >= 2) {
-            const uint32_t nvi = (i >= 0 && i < n_ok) ? hb >> 1 : 0u;
-            const uint32_t incl_v = wave_incl_sum32(nvi);
-            const uint64_t full = __ballot(i >= 0 && i < n_ok && incl_v >= ucnt - o32);   // the run that completes the count
-            const int n_take = full ? (int)__builtin_ctzll(full) - slot0 + 1 : n_ok;
-            const bool mine = i >= 0 && i < n_take;
-            const uint32_t iti = mine ? (nvi + 7u) >> 3 : 0u;
-            const uint32_t incl_i = wave_incl_sum32(iti);
-            if (mine) {
-              const uint32_t start = o32 + incl_v - nvi;
-              ex = start; ey = vi; ez = items + incl_i - iti; rg = 0xFFFFFFFFu;
-              const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
-              const uint32_t kt = (start + kTile - 1) & ~(uint32_t)(kTile - 1);
-              if (kt < endc) tile_run[kt / kTile] = make_int2(nr + i, (int)(qi - a));   // a run of < 64 values meets at most one tile start
-            }
-            const int last = slot0 + n_take - 1;
-            o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, last);
-            items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, last);
-            nr += n_take;
-            q += (uint32_t)n_take * stride;
-            if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
-            emit_end = o32;
-            emit_q = q;
-            if (n_take < 8) dense = false;
-            continue;
+          if (n_ok < 2) { dense = false; break; }
+          const uint32_t nvi = (i >= 0 && i < n_ok) ? hb >> 1 : 0u;
+          const uint32_t incl_v = wave_incl_sum32(nvi);
+          const uint64_t full = __ballot(i >= 0 && i < n_ok && incl_v >= ucnt - o32);   // the run that completes the count
+          const int n_take = full ? (int)__builtin_ctzll(full) - slot0 + 1 : n_ok;
+          const bool mine = i >= 0 && i < n_take;
+          const uint32_t iti = mine ? (nvi + 7u) >> 3 : 0u;
+          const uint32_t incl_i = wave_incl_sum32(iti);
+          if (mine) {
+            const uint32_t start = o32 + incl_v - nvi;
+            ex = start; ey = vi; ez = items + incl_i - iti;
+            const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
+            const uint32_t kt = (start + kTile - 1) & ~(uint32_t)(kTile - 1);
+            if (kt < endc) tile_run[kt / kTile] = make_int2(nr + i, (int)(qi - a));   // a run of < 64 values meets at most one tile start
           }
-          dense = false;
+          const int last = slot0 + n_take - 1;
+          o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, last);
+          items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, last);
+          nr += n_take;
+          q += (uint32_t)n_take * stride;
+          if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+          emit_end = o32;
+          emit_q = q;
+          if (n_take < 8) { dense = false; break; }
         }
-        const uint32_t run_q = q;
-        const uint32_t di = (q - wq) >> 2;
-        const uint32_t sh = (q & 3u) * 8u;
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
-        const uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
-        const uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
-        const uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
-        const uint32_t x1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
-        const uint32_t two = (x0 >> 7) & 1u;
-        if (__builtin_expect((x0 & 0x8080u) == 0x8080u, 0)) break;  // header of 3 or more bytes
-        const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
-        const uint32_t hlen = 1u + two;
-        const uint32_t isbp = header & 1u;
-        const uint32_t cg = header >> 1;
-        const uint32_t nv = cg << (isbp * 3u);
-        const uint32_t nbytes = ((cg * (uint32_t)w) & (0u - isbp)) | (nb_rle & (isbp - 1u));
-        const uint32_t val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen)) & rle_mask;
-        const uint32_t bpm = 0u - isbp;  // all ones for a bit-packed run
-        const uint32_t e_y = ((q + hlen - a) & bpm) | (val & ~bpm);
-        const uint32_t e_x = (isbp << 31) | o32;
-        const uint32_t nq = q + hlen + nbytes;
-        q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
-        if (__builtin_expect(nv == 0, 0)) continue;
-        const uint32_t endv = o32 + nv;
-        const uint32_t endc = endv < ucnt ? endv : ucnt;
-        const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);
-        if (__builtin_expect(kt < endc, 0))
-          for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
-            tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
-        if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; rg = (isbp | two) - 1u; }
-        nr++;
-        items += (nv + 7u) >> 3;
-        if (__builtin_expect((nr & 63) == 0, 0)) {
-          runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
-          dense = __builtin_popcountll(__ballot(rg != 0u)) >= 48;  // most of these 64 runs: RLE with a one-byte header
-        }
-        emit_end = endv;
-        emit_q = q;
-        o32 = endv;
+        if (dense) break;   // the window or the count ended the stretch: the mode carries over
       }
       if (out < (uint64_t)ucnt) out = o32;
     }
