@@ -354,6 +354,45 @@ def test_chunk_read_into_the_handles_input_buffer(dec, oracle):
         assert g.status == o.status == 0 and np.array_equal(g.values, o.values)
 
 
+def test_handles_on_several_threads(oracle):
+    # one handle per thread, as the reference runs one goroutine per column (reader/reader.go:306-327): decodes
+    # overlap on the device, results must not depend on who else is running
+    import threading
+    import parquet_go_amd as pq
+    rng = np.random.default_rng(4711)
+    jobs = []
+    for t in range(6):
+        w = [3, 12, 16, 1, 8, 20][t]
+        nd = min(1 << w, 70000)
+        cb = pg.ChunkBuilder(gap=t)
+        cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+        for n in (30000, 100000, 5):
+            cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, nd, n), w, rng))
+        chunk, pages = cb.finish()
+        jobs.append((chunk, pages, oracle.read_chunk(chunk, pages, pg.INT32)))
+    errors = []
+
+    def work(k):
+        try:
+            d = pq.Decoder(0)
+            chunk, pages, o = jobs[k]
+            for _ in range(8):
+                g = d.decode(chunk, pages, pg.INT32)
+                if g.status != 0 or not np.array_equal(g.values, o.values):
+                    errors.append("thread %d: result differs" % k)
+                    break
+            d.close()
+        except Exception as e:   # surfaces in the main thread below
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_delta_byte_array_length_classes(dec, oracle):
     # pages of short strings (one 64-byte row of lanes), of strings up to 1 KiB (previous string kept in LDS) and with
     # longer ones (parent-chain kernels), batches that mix the first two, and a prefix that overruns its predecessor
