@@ -35,7 +35,8 @@ def _keys(rng, n, hi=40):
     return out
 
 
-KINDS = ["dict32", "dict_ba", "plain64", "plain_ba", "delta32", "delta64", "dlba", "dba", "bool", "bss"]
+KINDS = ["dict32", "dict_ba", "plain64", "plain_ba", "delta32", "delta64", "dlba", "dba", "bool", "bss",
+         "dict_flba", "plain96", "dict64"]
 
 
 def base_case(kind, rng):
@@ -52,6 +53,16 @@ def base_case(kind, rng):
         ptype = pg.BYTE_ARRAY
         words = _strings(rng, 40, 0, 12)
         cb.dict_page(pg.plain_byte_array(words), len(words))
+    elif kind == "dict_flba":
+        ptype, tl = pg.FIXED_LEN_BYTE_ARRAY, 5
+        nd = 300
+        cb.dict_page(rng.integers(0, 256, nd * tl, dtype=np.uint8).tobytes(), nd)
+    elif kind == "dict64":
+        ptype = pg.INT64
+        nd = 20000
+        cb.dict_page(rng.integers(0, 256, nd * 8, dtype=np.uint8).tobytes(), nd)
+    elif kind == "plain96":
+        ptype = pg.INT96
     elif kind in ("plain64", "delta64"):
         ptype = pg.INT64
     elif kind in ("plain_ba", "dlba", "dba"):
@@ -68,6 +79,12 @@ def base_case(kind, rng):
             body, enc = pg.dict_indices_body(rng.integers(0, nd, nn), w, rng), pg.ENC_RLE_DICTIONARY
         elif kind == "dict_ba":
             body, enc = pg.dict_indices_body(rng.integers(0, len(words), nn), 6, rng), pg.ENC_PLAIN_DICTIONARY
+        elif kind == "dict_flba":
+            body, enc = pg.dict_indices_body(rng.integers(0, nd, nn), 9, rng), pg.ENC_RLE_DICTIONARY
+        elif kind == "dict64":
+            body, enc = pg.dict_indices_body(rng.integers(0, nd, nn), 15, rng), pg.ENC_PLAIN_DICTIONARY
+        elif kind == "plain96":
+            body, enc = rng.integers(0, 256, nn * 12, dtype=np.uint8).tobytes(), pg.ENC_PLAIN
         elif kind == "plain64":
             body, enc = rng.integers(-2**62, 2**62, nn, dtype=np.int64).tobytes(), pg.ENC_PLAIN
         elif kind == "plain_ba":
@@ -102,7 +119,7 @@ def mutate(chunk, pages, rng):
     pages = pages.copy()
     data = [i for i in range(pages.size) if pages["page_type"][i] != pg.DICTIONARY_PAGE] or list(range(pages.size))
     for _ in range(int(rng.integers(1, 4))):
-        i = int(rng.choice(data))
+        i = int(rng.choice(data)) if rng.integers(0, 8) else int(rng.integers(0, pages.size))   # one edit in eight may hit the dictionary page
         off, ln = int(pages["offset"][i]), int(pages["length"][i])
         op = int(rng.integers(0, 10))
         if op <= 4 and ln > 0:      # flip bytes, mostly near the start where the level sections and headers are
