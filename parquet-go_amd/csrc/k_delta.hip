@@ -345,6 +345,8 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
       }
       const T min_delta = DeltaTraits<T>::zigzag(md);
       if ((uint64_t)q + n_mb > (uint64_t)q_end) { status = PQD_ERR_EOF; break; }
+      // a miniblock of more than 2^30 values stands for the reference running out of memory in ReadBitPacked
+      if (groups > (1ull << 27)) { status = PQD_ERR_MALFORMED; break; }
       const uint32_t wq = q;
       q += (uint32_t)n_mb;
       for (uint64_t m = 0; m < n_mb && produced < n_values; m++) {
@@ -356,7 +358,9 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
           uint64_t nbytes = groups * wm;
           q += (uint32_t)(nbytes < (uint64_t)(q_end - q) ? nbytes : (uint64_t)(q_end - q));
         }
-        for (uint64_t i0 = 0; i0 < vpm; i0 += 64) {
+        // (values beyond the stream's count are decoded by the reference and then dropped: only the bytes count)
+        const uint64_t want = n_values - produced < vpm ? n_values - produced : vpm;
+        for (uint64_t i0 = 0; i0 < want; i0 += 64) {
           const uint64_t i = i0 + lane;
           T t = 0;
           if (i < vpm) t = (T)(wm ? gextract(base16, sm, i * wm, wm, q_end) : 0) + min_delta;
