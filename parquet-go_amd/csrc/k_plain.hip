@@ -28,10 +28,12 @@ __device__ __forceinline__ int plain_fixed_status(int ptype, int64_t len, int64_
   return PQD_OK;
 }
 
-// Copies `n` bytes src -> dst (both arbitrarily aligned), bytes at or beyond `src_avail` read as zero.
+// Copies `n` bytes src -> dst (both arbitrarily aligned), bytes at or beyond `src_avail` read as zero - or, with
+// `prev` > 0, as the byte `prev` positions earlier: ReadPlainINT96 reads every value into the same 12-byte buffer
+// (encodingread.go:74-80), so a last value cut short keeps the tail of the value before it.
 // Called by a whole block; `first` is the block's first byte.
 __device__ __forceinline__ void block_copy_tile(const uint8_t *src, int64_t src_avail, uint8_t *dst, int64_t n,
-                                                int64_t first, int tile_bytes) {
+                                                int64_t first, int tile_bytes, int prev = 0) {
   const int tid = threadIdx.x;
   for (int o = tid * 16; o < tile_bytes; o += 256 * 16) {
     const int64_t b = first + o;
@@ -39,7 +41,8 @@ __device__ __forceinline__ void block_copy_tile(const uint8_t *src, int64_t src_
     if (b + 16 <= n && b + 16 <= src_avail) {
       *reinterpret_cast<V16Unaligned *>(dst + b) = *reinterpret_cast<const V16Unaligned *>(src + b);
     } else {
-      for (int k = 0; k < 16 && b + k < n; k++) dst[b + k] = (b + k < src_avail) ? src[b + k] : (uint8_t)0;
+      for (int k = 0; k < 16 && b + k < n; k++)
+        dst[b + k] = (b + k < src_avail) ? src[b + k] : (prev > 0 && b + k >= prev && b + k - prev < src_avail ? src[b + k - prev] : (uint8_t)0);
     }
   }
 }
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_dict_plain_fixed(ChunkCtx c, int dict_p
     if (st) set_status1(&c.state[dict_page].status, st);
   }
   for (int64_t first = (int64_t)blockIdx.x * kPlainTile; first < bytes; first += (int64_t)gridDim.x * kPlainTile)
-    block_copy_tile(c.in + pi.body_off, pi.body_len, dict_out, bytes, first, kPlainTile);
+    block_copy_tile(c.in + pi.body_off, pi.body_len, dict_out, bytes, first, kPlainTile, c.physical_type == PQD_INT96 ? 12 : 0);
 }
 
 // ---- data pages, PLAIN fixed-width values ----
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k_plain_fixed(PlainArgs a) {
     const int64_t first = (int64_t)k * kPlainTile;
     if (first >= bytes) continue;
     block_copy_tile(c.in + ps->val_off, ps->val_len, a.values_out + ps->dense_base * (int64_t)c.elem_size, bytes, first,
-                    kPlainTile);
+                    kPlainTile, c.physical_type == PQD_INT96 ? 12 : 0);
   }
 }
 

@@ -354,6 +354,27 @@ def test_chunk_read_into_the_handles_input_buffer(dec, oracle):
         assert g.status == o.status == 0 and np.array_equal(g.values, o.values)
 
 
+def test_int96_cut_short_keeps_the_previous_values_tail(dec, oracle):
+    # ReadPlainINT96 reads every value into one 12-byte buffer (encodingread.go:71-82): a last value cut short keeps
+    # the tail of the value before it (zeros when it is the first); the same for an INT96 dictionary page
+    rng = np.random.default_rng(96)
+    for n, cut in ((5, 7), (1, 5), (300, 1), (300, 11)):
+        body = rng.integers(1, 256, n * 12, dtype=np.uint8).tobytes()
+        cb = pg.ChunkBuilder(gap=3)
+        cb.data_page_v1(pg.ENC_PLAIN, n, body[:len(body) - cut])
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, pg.INT96)
+        assert o.status == 0
+        if n > 1:
+            assert bytes(g.values[-1][12 - cut:]) == body[(n - 1) * 12 - cut:(n - 1) * 12]
+    cb = pg.ChunkBuilder()
+    body = rng.integers(1, 256, 40 * 12, dtype=np.uint8).tobytes()
+    cb.dict_page(body[:-5], 40)
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 500, pg.dict_indices_body(rng.integers(0, 40, 500), 6, rng))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT96)
+
+
 def test_handles_on_several_threads(oracle):
     # one handle per thread, as the reference runs one goroutine per column (reader/reader.go:306-327): decodes
     # overlap on the device, results must not depend on who else is running
