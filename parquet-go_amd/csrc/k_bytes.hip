@@ -70,11 +70,12 @@ __global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
 // lens[dense_base + i]) -> pairs; the bytes of value i start where value i-1 ended, the first at the end of
 // the length stream (PageState.aux0).  One block per data page, running carry.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *lens, uint64_t *pairs_out) {
-  __shared__ int64_t s_scan[256];
+__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out) {
+  constexpr int kPer = 4;  // consecutive values per thread and round
+  __shared__ int64_t s_wave[4];
   __shared__ int64_t s_carry;
   __shared__ int s_bad, s_refused;
-  const int d = blockIdx.x, tid = threadIdx.x;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != encoding) return;
   PageState *ps = &c.state[p];
@@ -83,26 +84,35 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
   const int64_t end = ps->val_off + ps->val_len;
   if (tid == 0) { s_carry = ps->aux0; s_bad = 0; s_refused = 0; }
   __syncthreads();
-  for (int64_t i0 = 0; i0 < cnt; i0 += 256) {
-    const int64_t i = i0 + tid;
-    int64_t ln = i < cnt ? lens[base + i] : 0;
-    if (ln < 0) { s_bad = 1; ln = 0; }  // make([]byte, huge) panics in the reference
-    if (ln > kMaxStrLen) { s_refused = 1; ln = 0; }
-    s_scan[tid] = ln;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-      int64_t t = tid >= o ? s_scan[tid - o] : 0;
-      __syncthreads();
-      s_scan[tid] += t;
-      __syncthreads();
+  for (int64_t i0 = 0; i0 < cnt; i0 += 256 * kPer) {
+    const int64_t carry = s_carry;
+    int64_t ln[kPer], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int64_t i = i0 + (int64_t)tid * kPer + j;
+      ln[j] = i < cnt ? lens[base + i] : 0;
+      if (ln[j] < 0) { s_bad = 1; ln[j] = 0; }  // make([]byte, huge) panics in the reference
+      if (ln[j] > kMaxStrLen) { s_refused = 1; ln[j] = 0; }
+      sum += ln[j];
     }
-    const int64_t src = s_carry + s_scan[tid] - ln;
-    if (i < cnt) {
-      if (ln > 0 && src + ln > end) s_refused = 1;  // the reference would zero pad a cut string (or hit EOF at the next one)
-      pairs_out[base + i] = make_pair(src, ln);
+    // exclusive scan of the threads' sums: shuffles inside the wave, LDS across the four waves
+    int64_t x = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();   // also: every thread has read s_carry
+    int64_t src = carry + x - sum;
+    for (int k = 0; k < wave; k++) src += s_wave[k];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int64_t i = i0 + (int64_t)tid * kPer + j;
+      if (i < cnt) {
+        if (ln[j] > 0 && src + ln[j] > end) s_refused = 1;  // the reference would zero pad a cut string (or hit EOF at the next one)
+        pairs_out[base + i] = make_pair(src, ln[j]);
+      }
+      src += ln[j];
     }
-    __syncthreads();
-    if (tid == 255) s_carry += s_scan[255];
+    if (tid == 255) s_carry = src;   // the last thread ends where the round ends
     __syncthreads();
   }
   if (tid == 0) {
