@@ -16,9 +16,6 @@ struct U32x4Unaligned { uint32_t v[4]; } __attribute__((packed));
 struct U64x2Unaligned { uint64_t v[2]; } __attribute__((packed));
 struct U64Unaligned { uint64_t v; } __attribute__((packed));
 
-#ifndef PQD_EXP
-#define PQD_EXP 0  // experiment switches for timing studies (results are wrong when non-zero)
-#endif
 constexpr int kSegBytes = 128;  // run index of the first item of every 64-item segment of a tile (32 entries)
 
 struct ExpandArgs {
@@ -240,7 +237,7 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       s_mark[q] = 0;  // left clean for the next tile
       r = r > m ? r : m;
     }
-    if (!(PQD_EXP & 8)) r = wave_incl_max(r);
+    r = wave_incl_max(r);
     if (!active) continue;
     const RunEntry e = s_runs[r];
     const int next_rel = (int)(s_runs[r + 1].x & 0x7FFFFFFFu) - d.t0;
@@ -253,9 +250,7 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
     const bool bp = e.x >> 31;
     if (bp) {
       const uint32_t rel = e.y - (uint32_t)d.org + kk * (uint32_t)W;
-      if ((PQD_EXP & 4) != 0) {
-        for (int j = 0; j < 8; j++) x[j] = (kk + j) & 1u;
-      } else if (rel + (uint32_t)W + 8u <= staged) {
+      if (rel + (uint32_t)W + 8u <= staged) {
         unpack8<W>(s_stage, rel, x);
       } else {
         // a payload cut short by the end of the stream: bytes that are not there read as zero
@@ -283,8 +278,8 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       if (MODE == 4) {
         uint32_t y[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) y[j] = (PQD_EXP & 2) ? x[j] : dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
-        if (!(PQD_EXP & 1) || y[0] == 0x12345u) store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
+        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
+        store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
       } else {
         uint64_t y[8];
 #pragma unroll
@@ -395,17 +390,13 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
     int n_flag = 0;  // levels: nulls or rows counted by this thread
     bool bad_index = false;
     if (in_lds) {
-      switch ((PQD_EXP & 16) ? 99 : __builtin_amdgcn_readfirstlane(d.w)) {
-#ifdef PQD_ONLY_W
-        case PQD_ONLY_W: expand_items<MODE, DMODE, GT, PQD_ONLY_W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
-#else
+      switch (__builtin_amdgcn_readfirstlane(d.w)) {
 #define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
         PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
         PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
         PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
         PQD_CASE(25) PQD_CASE(26) PQD_CASE(27) PQD_CASE(28) PQD_CASE(29) PQD_CASE(30) PQD_CASE(31) PQD_CASE(32)
 #undef PQD_CASE
-#endif
         default: break;
       }
     } else if (valid) {

@@ -815,30 +815,6 @@ int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages) {
   return PQD_OK;
 }
 
-// Not part of the public header: prints the device-side page and stream tables of the last call.
-int pqd_debug_dump(pqd_handle *h) {
-  if (!h || !h->have_result) return PQD_ERR_INVALID_ARG;
-  Guard g(h->device);
-  std::vector<PageState> st((size_t)h->n_pages);
-  std::vector<Stream> ss((size_t)3 * h->nd);
-  if (h->n_pages) HIP_TRY(hipMemcpy(st.data(), h->ctx.state, sizeof(PageState) * st.size(), hipMemcpyDeviceToHost));
-  if (h->nd) HIP_TRY(hipMemcpy(ss.data(), h->ctx.streams, sizeof(Stream) * ss.size(), hipMemcpyDeviceToHost));
-  for (int p = 0; p < h->n_pages; p++) {
-    const PageState &x = st[(size_t)p];
-    const PageIn &pi = h->h_pages[(size_t)p];
-    std::fprintf(stderr, "page %d type %d enc %d nv %d body [%lld,+%lld) | status %d nulls %d rows %d cnt %d dense_base %lld val [%lld,+%lld) aux %lld %lld\n",
-                 p, pi.page_type, pi.encoding, pi.num_values, (long long)pi.body_off, (long long)pi.body_len, x.status, x.n_nulls,
-                 x.n_rows, x.cnt, (long long)x.dense_base, (long long)x.val_off, (long long)x.val_len, (long long)x.aux0, (long long)x.aux1);
-  }
-  for (size_t i = 0; i < ss.size(); i++) {
-    const Stream &x = ss[i];
-    std::fprintf(stderr, "stream %zu (group %zu) off %lld len %d avail %d w %d cnt %d out_base %lld run_base %lld cap %d tile_base %d page %d | n_runs %d status %d decoded %lld pad %d\n",
-                 i, h->nd ? i / (size_t)h->nd : 0, (long long)x.off, x.len, x.avail, x.w, x.cnt, (long long)x.out_base, (long long)x.run_base,
-                 x.run_cap, x.tile_base, x.page, x.n_runs, x.status, (long long)x.decoded, x.pad);
-  }
-  return PQD_OK;
-}
-
 int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out) {
   if (!h || !n_out) return fail_arg("NULL argument");
   Guard g(h->device);
