@@ -185,8 +185,16 @@ __device__ __forceinline__ uint32_t wave_incl_sum32(uint32_t x) {
 }
 }  // namespace
 
+// Jump stretches (kJump): resolving a span of short runs at once
+constexpr int kSpan = 2048;          // byte positions one jump step covers: 32 per lane
+constexpr uint32_t kJumpRunBytes = 32;  // the step is taken while runs average fewer bytes than this ...
+constexpr uint32_t kJumpStayBytes = 64; // ... and kept up while they average fewer than this
+
+template <bool kJump>
 __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   __shared__ uint4 win4[kWinVec];
+  __shared__ __align__(16) uint16_t jt[kJump ? kSpan + 8 : 8];  // successor of every position of a span (jt[kSpan]: beyond it); later the positions visited, in order
+  __shared__ uint32_t mk[kJump ? 64 : 1];                        // bit b of mk[l]: position 32 l + b is a header the walk visits
   const uint32_t *win = reinterpret_cast<const uint32_t *>(win4);
   const int lane = threadIdx.x;
   Stream *sp = &c.streams[s0 + blockIdx.x];
@@ -227,6 +235,8 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   uint32_t items = 0;              // work items of the runs emitted so far
   int status = PQD_OK;
   bool dense = false;              // most of the last 64 runs were one-byte-header RLE runs: try whole strides of them at once
+  bool jumpy = false;              // the last 64 runs were short: resolve whole spans of them at once
+  uint32_t flush_q = a;            // position after the run that completed the last group of 64
 
   // Outer loop: one LDS window [wq, wq + kWin + 64); inner loop: the runs whose header starts in
   // [wq, wq + kWin).  The next window is in flight (registers) while the current one is walked.
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
       // (nr cannot reach run_cap here: every emitted run holds a value below cnt and takes a byte of the stream)
       for (;;) {
         // one run at a time; the loop bound drops to 0 when the 64 runs of a flush say the stream is dense
-        uint32_t hot_lim = dense ? 0u : lim;
+        uint32_t hot_lim = (dense || jumpy) ? 0u : lim;
         bool long_header = false;
         while (q < hot_lim && o32 < ucnt) {
           const uint32_t run_q = q;
@@ -292,13 +302,145 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
             const uint32_t nxt = (uint32_t)__shfl_down((int)(ex & 0x7FFFFFFFu), 1);
             const uint32_t nvl = (lane == 63 ? endv : nxt) - (ex & 0x7FFFFFFFu);
             dense = __builtin_popcountll(__ballot((ex >> 31) == 0u && nvl < 64u)) >= 48;
-            if (dense) hot_lim = 0u;
+            if (kJump) { jumpy = !dense && q - flush_q < 64u * kJumpRunBytes; flush_q = q; }
+            if (dense || jumpy) hot_lim = 0u;
           }
           emit_end = endv;
           emit_q = q;
           o32 = endv;
         }
-        if (!dense || long_header) break;
+        if (long_header || !(dense || jumpy)) break;
+        if (kJump && !dense) {
+          // Jump stretch.  Many short runs of any shape (Arrow-style level streams: a few values per run): the chain
+          // of headers inside a span of kSpan bytes is resolved by all lanes together instead of one header at a
+          // time.  Every lane works out, for each of its 32 byte positions, where the next header would be if a
+          // header started there (1- or 2-byte headers of non-empty runs that end inside the stream; any other
+          // position is its own successor and ends the chain).  Squaring that successor table log2(runs) times
+          // while marking the successors of marked positions, starting from the one position known to be a header,
+          // marks exactly the headers the one-at-a-time walk would visit.  They are then recorded 64 per step with
+          // prefix sums, cut at the run that completes the count.
+          while (q < lim && o32 < ucnt) {
+            const uint32_t q0 = q;
+            const uint32_t pl = q0 + 32u * (uint32_t)lane;  // the first of this lane's positions
+            uint32_t okw = 0;                               // bit k: a run the table covers starts at pl + k
+            uint32_t jp[16];                                // successors of this lane's positions, two per dword
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+              const uint32_t p = 32u * (uint32_t)lane + 2u * (uint32_t)k;
+              jp[k] = p | ((p + 1u) << 16);
+            }
+            if (pl < lim) {
+              const uint32_t dj = (pl - wq) >> 2, sj = (pl & 3u) * 8u;
+              uint32_t d[10], b[9];
+#pragma unroll
+              for (int i = 0; i < 10; i++) d[i] = win[dj + i];
+#pragma unroll
+              for (int i = 0; i < 9; i++) b[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], sj);
+#pragma unroll
+              for (int k = 0; k < 32; k++) {
+                const uint32_t x = ((k & 3) == 3 ? ((b[k >> 2] >> 24) | (b[(k >> 2) + 1] << 8)) : (b[k >> 2] >> (8 * (k & 3)))) & 0xFFFFu;
+                const uint32_t two = (x >> 7) & 1u;
+                const uint32_t header = (x & 0x7Fu) | (two ? ((x >> 1) & 0x3F80u) : 0u);
+                const uint32_t isbp = header & 1u, cg = header >> 1;
+                const uint32_t adv = 1u + two + (isbp ? cg * (uint32_t)w : nb_rle);
+                const uint32_t pq = pl + (uint32_t)k;
+                const bool ok = (x & 0x8080u) != 0x8080u && cg != 0u && pq < lim && pq + adv <= qend;
+                if (ok) {
+                  const uint32_t p = 32u * (uint32_t)lane + (uint32_t)k;
+                  const uint32_t j = p + adv < (uint32_t)kSpan ? p + adv : (uint32_t)kSpan;
+                  okw |= 1u << k;
+                  jp[k >> 1] = (k & 1) ? ((jp[k >> 1] & 0xFFFFu) | (j << 16)) : ((jp[k >> 1] & 0xFFFF0000u) | j);
+                }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              reinterpret_cast<uint4 *>(jt)[4 * lane + i] = make_uint4(jp[4 * i], jp[4 * i + 1], jp[4 * i + 2], jp[4 * i + 3]);
+            if (lane == 0) jt[kSpan] = (uint16_t)kSpan;
+            mk[lane] = lane == 0 ? 1u : 0u;
+            __syncthreads();
+            // at the start of round r the table holds the 2^r-th successors and the marks every header fewer than
+            // 2^r runs away from q0; a span holds at most kSpan / 2 runs
+            uint32_t m_prev = 0;
+            for (int r = 0; r < 12; r++) {
+              const uint32_t m = mk[lane];
+              if (r > 0 && __ballot(m != m_prev) == 0ull) break;
+              m_prev = m;
+              uint32_t jn[16];
+#pragma unroll
+              for (int k = 0; k < 32; k++) {
+                const uint32_t j = (jp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                if (((m >> k) & 1u) && j < (uint32_t)kSpan) atomicOr(&mk[j >> 5], 1u << (j & 31u));
+                const uint32_t jj = jt[j];
+                jn[k >> 1] = (k & 1) ? (jn[k >> 1] | (jj << 16)) : jj;
+              }
+              __syncthreads();
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                reinterpret_cast<uint4 *>(jt)[4 * lane + i] = make_uint4(jn[4 * i], jn[4 * i + 1], jn[4 * i + 2], jn[4 * i + 3]);
+#pragma unroll
+              for (int k = 0; k < 16; k++) jp[k] = jn[k];
+              __syncthreads();
+            }
+            // the visited headers of runs, in order, into jt
+            const uint32_t mv = mk[lane] & okw;
+            const uint32_t n_l = (uint32_t)__builtin_popcount(mv);
+            const uint32_t incl_l = wave_incl_sum32(n_l);
+            const int total = __builtin_amdgcn_readlane((int)incl_l, 63);
+            {
+              uint32_t idx = incl_l - n_l;
+              for (uint32_t mm = mv; mm; mm &= mm - 1u) jt[idx++] = (uint16_t)(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm));
+            }
+            __syncthreads();
+            int taken = 0;
+            while (taken < total && o32 < ucnt) {
+              const int slot0 = nr & 63;                 // pending entries sit in lanes [0, slot0)
+              const int i = lane - slot0;
+              int n_av = total - taken;
+              if (n_av > 64 - slot0) n_av = 64 - slot0;
+              const bool in = i >= 0 && i < n_av;
+              const uint32_t qi = q0 + (in ? (uint32_t)jt[taken + i] : 0u);
+              const uint32_t dj = (qi - wq) >> 2, sj = (qi & 3u) * 8u;
+              const uint32_t d0 = win[dj], d1 = win[dj + 1], d2 = win[dj + 2];
+              const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sj), x1 = __builtin_amdgcn_alignbit(d2, d1, sj);
+              const uint32_t two = (x0 >> 7) & 1u;
+              const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
+              const uint32_t hlen = 1u + two, isbp = header & 1u, cg = header >> 1;
+              const uint32_t adv = hlen + (isbp ? cg * (uint32_t)w : nb_rle);
+              const uint32_t val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen)) & rle_mask;
+              const uint32_t e_y = isbp ? qi + hlen - a : val;
+              const uint32_t nvi = in ? cg << (isbp * 3u) : 0u;
+              const uint32_t incl_v = wave_incl_sum32(nvi);
+              const uint64_t full = __ballot(in && incl_v >= ucnt - o32);   // the run that completes the count
+              const int n_take = full ? (int)__builtin_ctzll(full) - slot0 + 1 : n_av;
+              const bool mine = i >= 0 && i < n_take;
+              const uint32_t iti = mine ? (nvi + 7u) >> 3 : 0u;
+              const uint32_t incl_i = wave_incl_sum32(iti);
+              if (mine) {
+                const uint32_t start = o32 + incl_v - nvi;
+                ex = (isbp << 31) | start; ey = e_y; ez = items + incl_i - iti;
+                const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
+                for (uint32_t kt = (start + kTile - 1) / kTile; kt * (uint32_t)kTile < endc; kt++)
+                  tile_run[kt] = make_int2(nr + i, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(kt * (uint32_t)kTile - start) * (uint32_t)w) >> 3) : qi - a));
+              }
+              const int last = slot0 + n_take - 1;
+              o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, last);
+              items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, last);
+              q = (uint32_t)__builtin_amdgcn_readlane((int)(qi + adv), last);
+              nr += n_take;
+              taken += n_take;
+              if ((nr & 63) == 0) runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+              emit_end = o32;
+              emit_q = q;
+            }
+            __syncthreads();  // the list is rewritten by the next step
+            // a header of another kind at q, or runs that have grown long: back to one run at a time
+            if (total == 0 || q - q0 > (uint32_t)total * kJumpStayBytes) { jumpy = false; break; }
+          }
+          if (jumpy) break;   // the window or the count ended the stretch: the mode carries over
+          flush_q = q;
+          continue;
+        }
         // Dense stretch (the reference's own writer emits nothing else, encodingwrite.go:149-214: one RLE run per
         // change of value, a one-byte header and the value): as long as every run is of that shape the headers
         // sit at a fixed stride, so every lane checks the header one stride further on and the leading lanes
@@ -612,10 +754,11 @@ hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, hipStream_t stream) {
+hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bool jump, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   if (wide) return launch_hybrid_prescan_wide(c, s0, n, stream);
-  hipLaunchKernelGGL(k_hybrid_prescan, dim3(n), dim3(64), 0, stream, c, s0);
+  if (jump) hipLaunchKernelGGL(k_hybrid_prescan<true>, dim3(n), dim3(64), 0, stream, c, s0);
+  else hipLaunchKernelGGL(k_hybrid_prescan<false>, dim3(n), dim3(64), 0, stream, c, s0);
   return hipGetLastError();
 }
 

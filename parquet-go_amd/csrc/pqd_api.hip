@@ -390,6 +390,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   bool wide_levels = wide_dict && slots / nd >= 256 * 1024;
   if (force && force[0] == 'w' && force[1] == 'i') wide_dict = wide_levels = true;
   if (force && force[0] == 'w' && force[1] == 'a') wide_dict = wide_levels = false;
+  // Level streams of nullable and nested columns are where runs of a few values each are the rule; dictionary
+  // indices get the same treatment unless other chunks' expansions want the LDS (PQD_JUMP=0|1 pins it).
+  bool jump_levels = true, jump_dict = !shared_gpu;
+  if (const char *fj = std::getenv("PQD_JUMP")) jump_levels = jump_dict = fj[0] == '1';
 
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = heavy_stream(h->device);
@@ -409,7 +413,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (n_pages > 0) {
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
-      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, jump_levels, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
         HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
@@ -429,7 +433,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if (any_dict_enc) {
       if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
       else {
-        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
+        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
         HIP_TRY(to_heavy());
         { Prof pf(h, "k_hybrid_expand<dict>", heavy);
           HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
@@ -496,7 +500,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (any_dict_enc) {
     if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
     else {
-      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);
         HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out,

@@ -10,7 +10,8 @@ namespace pqd {
 hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream);
 // streams [s0, s0 + n): one wavefront walks the run headers of each stream
 // wide: one 576-thread workgroup per stream (few long streams) instead of one wavefront per stream
-hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, hipStream_t stream);
+// jump: the wavefront variant that also resolves spans of short runs at once (4 KiB more LDS per stream)
+hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bool jump, hipStream_t stream);
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)

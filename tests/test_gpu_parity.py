@@ -189,6 +189,81 @@ def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant, m
     check_same(dec, oracle, chunk, pages, pg.INT32, 0, 3, 2)
 
 
+@pytest.mark.parametrize("jump", ["1", "0"])
+@pytest.mark.parametrize("w", [1, 2, 3, 5, 8, 9, 16, 20, 32])
+def test_short_runs_resolved_a_span_at_a_time(dec, oracle, w, jump, monkeypatch):
+    # Arrow-style streams: a few values per run, bit-packed groups and RLE runs mixed, so that the headers follow no
+    # fixed stride; now and then a run with a two-byte header, one long enough to leave the span or the window, an
+    # empty run of either kind and a three-byte header (none of which the successor table covers); pages whose
+    # count ends inside a span; the same as definition / repetition levels
+    monkeypatch.setenv("PQD_PRESCAN", "wave")
+    monkeypatch.setenv("PQD_JUMP", jump)
+    rng = np.random.default_rng(4400 + w)
+    nd = min(1 << w, 5000)
+    nb = (w + 7) // 8
+
+    def short_runs(n_target, odd_every):
+        out, vals = bytearray(), []
+        while len(vals) < n_target:
+            kind = int(rng.integers(0, odd_every))
+            if kind == 0:      # two-byte header, RLE
+                c, v = int(rng.integers(64, 400)), int(rng.integers(0, nd))
+                out += pg.varint(c << 1) + v.to_bytes(4, "little")[:nb]
+                vals += [v] * c
+            elif kind == 1:    # two-byte header, bit-packed: up to a few KiB of payload
+                g = int(rng.integers(64, 64 + 2048 // w))
+                x = rng.integers(0, nd, 8 * g)
+                out += pg.varint((g << 1) | 1) + pg.bitpack(x, w)
+                vals += x.tolist()
+            elif kind == 2:    # empty RLE run
+                out += b"\x00" + bytes(nb)
+            elif kind == 3:    # empty bit-packed run
+                out += b"\x01"
+            elif kind == 4:    # three-byte header
+                c, v = int(rng.integers(8192, 9000)), int(rng.integers(0, nd))
+                out += pg.varint(c << 1) + v.to_bytes(4, "little")[:nb]
+                vals += [v] * c
+            elif kind % 2:
+                g = int(rng.integers(1, 4))
+                x = rng.integers(0, nd, 8 * g)
+                out += pg.varint((g << 1) | 1) + pg.bitpack(x, w)
+                vals += x.tolist()
+            else:
+                c, v = int(rng.integers(1, 20)), int(rng.integers(0, nd))
+                out += bytes([c << 1]) + v.to_bytes(4, "little")[:nb]
+                vals += [v] * c
+        return bytes(out), vals
+
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 7)), lead=int(rng.integers(0, 3)))
+    cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+    for n_target, odd_every in ((50, 40), (5000, 10**9), (30000, 2000), (120000, 300), (20000, 30)):
+        body, vals = short_runs(n_target, odd_every)
+        n = len(vals) - int(rng.integers(0, min(40, len(vals))))
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([w]) + body)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
+    assert o.status == 0
+    if w <= 3:
+        max_def = (1 << w) - 1
+        block = lambda body: len(body).to_bytes(4, "little") + body   # v1 level section (layout/page.go:234-238)
+        cb = pg.ChunkBuilder(gap=1)
+        for n in (300, 20000, 150000):
+            dl = rng.integers(0, max_def + 1, n)
+            rl = rng.integers(0, 2, n)
+            rl[0] = 0
+            for r in rng.integers(0, n, n // 40):
+                k = int(rng.integers(8, 60))
+                dl[r:r + k] = dl[r]
+                rl[r + 1:r + k] = 1
+            nn = int((dl == max_def).sum())
+            cb.data_page_v1(pg.ENC_PLAIN, n, rng.integers(-2**31, 2**31, nn, dtype=np.int64).astype(np.int32).tobytes(),
+                            block(pg.hybrid_encode(rl, 1, rng, "arrow", max_groups=2)),
+                            block(pg.hybrid_encode(dl, w, rng, "arrow", max_groups=3)))
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, pg.INT32, 0, max_def, 1)
+        assert o.status == 0
+
+
 @pytest.mark.parametrize("ptype,tl", [(pg.INT32, 0), (pg.INT64, 0), (pg.FLOAT, 0), (pg.DOUBLE, 0), (pg.INT96, 0),
                                       (pg.FIXED_LEN_BYTE_ARRAY, 7), (pg.BOOLEAN, 0)])
 def test_plain_fixed(dec, oracle, ptype, tl):
