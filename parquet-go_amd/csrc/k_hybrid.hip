@@ -187,14 +187,15 @@ __device__ __forceinline__ uint32_t wave_incl_sum32(uint32_t x) {
 
 // Jump stretches (kJump): resolving a span of short runs at once
 constexpr int kSpan = 2048;          // byte positions one jump step covers: 32 per lane
-constexpr uint32_t kJumpRunBytes = 32;  // the step is taken while runs average fewer bytes than this ...
-constexpr uint32_t kJumpStayBytes = 64; // ... and kept up while they average fewer than this
+constexpr uint32_t kJumpRunBytes = 64;  // the step is taken while runs average fewer bytes than this ...
+constexpr uint32_t kJumpStayBytes = 96; // ... and kept up while they average fewer than this
 
 template <bool kJump>
 __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   __shared__ uint4 win4[kWinVec];
-  __shared__ __align__(16) uint16_t jt[kJump ? kSpan + 8 : 8];  // successor of every position of a span (jt[kSpan]: beyond it); later the positions visited, in order
-  __shared__ uint32_t mk[kJump ? 64 : 1];                        // bit b of mk[l]: position 32 l + b is a header the walk visits
+  __shared__ __align__(16) uint16_t jt[kJump ? kSpan + 8 : 8];  // successor of every position of a span (jt[kSpan]: beyond it)
+  __shared__ uint16_t lst[kJump ? kSpan / 2 + 64 : 8];            // the headers the walk visits, in order
+  __shared__ uint32_t mk[kJump ? 64 : 1];                        // bit b of mk[l]: a run the successor table covers starts at position 32 l + b
   const uint32_t *win = reinterpret_cast<const uint32_t *>(win4);
   const int lane = threadIdx.x;
   Stream *sp = &c.streams[s0 + blockIdx.x];
@@ -356,50 +357,60 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
               reinterpret_cast<uint4 *>(jt)[4 * lane + i] = make_uint4(jp[4 * i], jp[4 * i + 1], jp[4 * i + 2], jp[4 * i + 3]);
-            if (lane == 0) jt[kSpan] = (uint16_t)kSpan;
-            mk[lane] = lane == 0 ? 1u : 0u;
+            mk[lane] = okw;
+            if (lane == 0) { jt[kSpan] = (uint16_t)kSpan; lst[0] = 0; lst[kSpan / 2] = (uint16_t)kSpan; }
             __syncthreads();
-            // at the start of round r the table holds the 2^r-th successors and the marks every header fewer than
-            // 2^r runs away from q0; a span holds at most kSpan / 2 runs
-            uint32_t m_prev = 0;
-            for (int r = 0; r < 12; r++) {
-              const uint32_t m = mk[lane];
-              if (r > 0 && __ballot(m != m_prev) == 0ull) break;
-              m_prev = m;
+            // For the squaring every lane keeps the pairs of positions {128 k + 2 lane, + 1}: neighbouring lanes then
+            // look up neighbouring table entries (with 32 consecutive positions per lane, as above, every lookup of a
+            // wave would fall into four LDS banks).
+            uint32_t *jt32 = reinterpret_cast<uint32_t *>(jt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) jp[k] = jt32[64 * k + lane];
+            // lst[d] = the header d runs after the one at q0.  With the table holding the len-th successors, the
+            // entries [len, 2 len) follow from the entries [0, len); then the table is squared.  A span holds at
+            // most kSpan / 2 runs; past the end of the chain the entries repeat its last position or kSpan.
+            int len = 1;
+            for (;;) {
+              if (len <= 64) {
+                if (lane < len) lst[len + lane] = jt[lst[lane]];
+              } else if (len == 128) {
+                const uint32_t p0 = lst[lane], p1 = lst[lane + 64];
+                const uint16_t j0 = jt[p0], j1 = jt[p1];
+                lst[128 + lane] = j0; lst[192 + lane] = j1;
+              } else {
+                for (int i = lane; i < len; i += 256) {   // (len is a multiple of 256 here)
+                  const uint32_t p0 = lst[i], p1 = lst[i + 64], p2 = lst[i + 128], p3 = lst[i + 192];
+                  const uint16_t j0 = jt[p0], j1 = jt[p1], j2 = jt[p2], j3 = jt[p3];
+                  lst[len + i] = j0; lst[len + i + 64] = j1; lst[len + i + 128] = j2; lst[len + i + 192] = j3;
+                }
+              }
+              __syncthreads();
+              len *= 2;
+              const uint32_t tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)lst[len - 1]);
+              const bool ended = tail >= (uint32_t)kSpan || ((mk[tail >> 5] >> (tail & 31u)) & 1u) == 0u;
+              if (__builtin_amdgcn_readfirstlane((int)ended) || len >= kSpan / 2) break;
               uint32_t jn[16];
 #pragma unroll
               for (int k = 0; k < 32; k++) {
-                const uint32_t j = (jp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                if (((m >> k) & 1u) && j < (uint32_t)kSpan) atomicOr(&mk[j >> 5], 1u << (j & 31u));
-                const uint32_t jj = jt[j];
+                const uint32_t jj = jt[(jp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
                 jn[k >> 1] = (k & 1) ? (jn[k >> 1] | (jj << 16)) : jj;
               }
               __syncthreads();
 #pragma unroll
-              for (int i = 0; i < 4; i++)
-                reinterpret_cast<uint4 *>(jt)[4 * lane + i] = make_uint4(jn[4 * i], jn[4 * i + 1], jn[4 * i + 2], jn[4 * i + 3]);
-#pragma unroll
-              for (int k = 0; k < 16; k++) jp[k] = jn[k];
+              for (int k = 0; k < 16; k++) { jt32[64 * k + lane] = jn[k]; jp[k] = jn[k]; }
               __syncthreads();
             }
-            // the visited headers of runs, in order, into jt
-            const uint32_t mv = mk[lane] & okw;
-            const uint32_t n_l = (uint32_t)__builtin_popcount(mv);
-            const uint32_t incl_l = wave_incl_sum32(n_l);
-            const int total = __builtin_amdgcn_readlane((int)incl_l, 63);
-            {
-              uint32_t idx = incl_l - n_l;
-              for (uint32_t mm = mv; mm; mm &= mm - 1u) jt[idx++] = (uint16_t)(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm));
-            }
-            __syncthreads();
             int taken = 0;
-            while (taken < total && o32 < ucnt) {
+            while (o32 < ucnt) {
               const int slot0 = nr & 63;                 // pending entries sit in lanes [0, slot0)
               const int i = lane - slot0;
-              int n_av = total - taken;
-              if (n_av > 64 - slot0) n_av = 64 - slot0;
+              const uint32_t p = (i >= 0 && taken + i < len) ? (uint32_t)lst[taken + i] : (uint32_t)kSpan;
+              const bool valid = p < (uint32_t)kSpan && ((mk[p < (uint32_t)kSpan ? p >> 5 : 0u] >> (p & 31u)) & 1u) != 0u;
+              const uint64_t vm = __ballot(valid) >> slot0;
+              const int n_av = vm == ~0ull ? 64 : (int)__builtin_ctzll(~vm);   // the runs of the chain not yet taken, up to the free lanes
+              if (n_av == 0) break;
               const bool in = i >= 0 && i < n_av;
-              const uint32_t qi = q0 + (in ? (uint32_t)jt[taken + i] : 0u);
+              const uint32_t qi = q0 + (in ? p : 0u);
               const uint32_t dj = (qi - wq) >> 2, sj = (qi & 3u) * 8u;
               const uint32_t d0 = win[dj], d1 = win[dj + 1], d2 = win[dj + 2];
               const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sj), x1 = __builtin_amdgcn_alignbit(d2, d1, sj);
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
             }
             __syncthreads();  // the list is rewritten by the next step
             // a header of another kind at q, or runs that have grown long: back to one run at a time
-            if (total == 0 || q - q0 > (uint32_t)total * kJumpStayBytes) { jumpy = false; break; }
+            if (taken == 0 || q - q0 > (uint32_t)taken * kJumpStayBytes) { jumpy = false; break; }
           }
           if (jumpy) break;   // the window or the count ended the stretch: the mode carries over
           flush_q = q;

@@ -36,7 +36,7 @@ def _keys(rng, n, hi=40):
 
 
 KINDS = ["dict32", "dict_ba", "plain64", "plain_ba", "delta32", "delta64", "dlba", "dba", "bool", "bss",
-         "dict_flba", "plain96", "dict64"]
+         "dict_flba", "plain96", "dict64", "dict_short"]
 
 
 def base_case(kind, rng):
@@ -48,6 +48,10 @@ def base_case(kind, rng):
     if kind == "dict32":
         w = int(rng.choice([1, 2, 3, 5, 8, 11, 16]))
         nd = min(1 << w, 3000)
+        cb.dict_page(rng.integers(0, 256, nd * 4, dtype=np.uint8).tobytes(), nd)
+    elif kind == "dict_short":     # runs of a few values each, in the indices and in the levels
+        w = int(rng.choice([1, 2, 3, 5, 8]))
+        nd = 1 << w
         cb.dict_page(rng.integers(0, 256, nd * 4, dtype=np.uint8).tobytes(), nd)
     elif kind == "dict_ba":
         ptype = pg.BYTE_ARRAY
@@ -71,11 +75,18 @@ def base_case(kind, rng):
         ptype = pg.BOOLEAN
     elif kind == "bss":
         ptype = pg.DOUBLE
+    mg = 2 if kind == "dict_short" else 63     # bit-packed groups per run at most
     for _ in range(int(rng.integers(2, 5))):
         n = int(rng.choice([1, 7, 64, 300, 1500, 5000]))
+        if kind == "dict_short":
+            n = int(rng.choice([700, 3000, 20000]))
         dl, rl = _levels(rng, n, max_def, max_rep)
         nn = int((dl == max_def).sum())
-        if kind == "dict32":
+        if kind == "dict_short":
+            idx = np.repeat(rng.integers(0, nd, nn // 3 + 1), rng.integers(1, 6, nn // 3 + 1))[:nn]
+            idx = np.concatenate([idx, rng.integers(0, nd, nn - len(idx))])
+            body, enc = bytes([w]) + pg.hybrid_encode(idx, w, rng, "mixed", mg), pg.ENC_RLE_DICTIONARY
+        elif kind == "dict32":
             body, enc = pg.dict_indices_body(rng.integers(0, nd, nn), w, rng), pg.ENC_RLE_DICTIONARY
         elif kind == "dict_ba":
             body, enc = pg.dict_indices_body(rng.integers(0, len(words), nn), 6, rng), pg.ENC_PLAIN_DICTIONARY
@@ -105,11 +116,11 @@ def base_case(kind, rng):
         if nn == 0 and kind in ("dlba", "dba", "delta32", "delta64"):
             body = b""
         if rng.integers(0, 3) == 0:
-            cb.data_page_v2(enc, n, body, pg.hybrid_encode(rl, max(1, int(max_rep).bit_length()), rng) if max_rep else b"",
-                            pg.hybrid_encode(dl, max(1, int(max_def).bit_length()), rng) if max_def else b"")
+            cb.data_page_v2(enc, n, body, pg.hybrid_encode(rl, max(1, int(max_rep).bit_length()), rng, "mixed", mg) if max_rep else b"",
+                            pg.hybrid_encode(dl, max(1, int(max_def).bit_length()), rng, "mixed", mg) if max_def else b"")
         else:
-            cb.data_page_v1(enc, n, body, pg.level_block_v1(rl, max_rep, rng) if max_rep else b"",
-                            pg.level_block_v1(dl, max_def, rng) if max_def else b"")
+            block = lambda lv, mx: (lambda b: len(b).to_bytes(4, "little") + b)(pg.hybrid_encode(lv, int(mx).bit_length(), rng, "mixed", mg))
+            cb.data_page_v1(enc, n, body, block(rl, max_rep) if max_rep else b"", block(dl, max_def) if max_def else b"")
     return cb, ptype, tl, max_def, max_rep
 
 
