@@ -4,6 +4,7 @@
 // Reference behaviour reproduced here: encoding/encodingread.go:13-125, encoding/binaryread.go:10-92
 // (PLAIN), layout/page.go:792-811 (dictionary page), :905-931 (value scatter).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "pqd_kernels.h"
 
 namespace pqd {
@@ -315,6 +316,112 @@ __global__ __launch_bounds__(256) void k_scatter_apply(const int32_t *def, int64
   }
 }
 
+// ---- null scatter straight from PLAIN pages (4- and 8-byte types, every data page PLAIN) ----
+// The dense intermediate of such a column would be a plain copy of the pages' value sections, so the scatter reads
+// the pages themselves: the value of the slot with rank r inside data page i sits at val_off[i] + (r - dense_base[i])
+// * size.  tile_page[t] = data page that holds slot t * kScatterTile.
+__global__ __launch_bounds__(256) void k_scatter_tile_pages(ChunkCtx c, int64_t n, int n_tiles, int32_t *tile_page) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  // (one thread per data page checks the page's length the way the copying kernel does, binaryread.go:12-18)
+  if (t < c.nd) {
+    const int p = c.streams[2 * c.nd + t].page;
+    PageState *ps = &c.state[p];
+    if (ps->status == 0 && c.pages[p].encoding == PQD_ENC_PLAIN) {
+      const int st = plain_fixed_status(c.physical_type, ps->val_len, ps->cnt, c.elem_size);
+      if (st) set_status1(&ps->status, st);
+    }
+  }
+  if (t > n_tiles) return;
+  if (t == n_tiles) { tile_page[t] = c.nd - 1; return; }
+  const int64_t s = (int64_t)t * kScatterTile;
+  int lo = 0, hi = c.nd;   // the last data page whose first slot is at or before s
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (c.pages[c.streams[2 * c.nd + mid].page].slot_base <= s) lo = mid; else hi = mid;
+  }
+  tile_page[t] = lo;
+}
+
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_scatter_apply_plain(ChunkCtx c, const int32_t *def, int64_t n, const int64_t *partial,
+                                                             const int32_t *tile_page, uint8_t *out) {
+  typedef typename std::conditional<ESZ == 8, uint64_t, uint32_t>::type T;
+  struct TU { T v; } __attribute__((packed));
+  __shared__ int s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int max_def = c.max_def;
+  const int64_t base = (int64_t)blockIdx.x * kScatterTile;
+  const int pg_lo = tile_page[blockIdx.x], pg_hi = tile_page[blockIdx.x + 1];
+  const Stream *vstreams = c.streams + 2 * c.nd;
+  int64_t rank0 = partial[blockIdx.x];
+#pragma unroll 1
+  for (int it = 0; it < kScatterTile / 1024; it++) {
+    const int64_t s0 = base + it * 1024 + tid * 4;
+    int4 d = make_int4(-1, -1, -1, -1);
+    if (s0 + 4 <= n) d = *reinterpret_cast<const int4 *>(def + s0);
+    else {
+      if (s0 < n) d.x = def[s0];
+      if (s0 + 1 < n) d.y = def[s0 + 1];
+      if (s0 + 2 < n) d.z = def[s0 + 2];
+    }
+    const bool vv[4] = {s0 < n && d.x == max_def, s0 + 1 < n && d.y == max_def, s0 + 2 < n && d.z == max_def,
+                        s0 + 3 < n && d.w == max_def};
+    const int cv = (int)vv[0] + (int)vv[1] + (int)vv[2] + (int)vv[3];
+    int incl = cv;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    __syncthreads();  // the previous round's totals have been read
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { if (q < wv) wbase += s_wave[q]; total += s_wave[q]; }
+    int64_t r = rank0 + wbase + incl - cv;
+    rank0 += total;
+    if (s0 >= n) continue;
+    // the data page of slot s0: the last one in [pg_lo, pg_hi] that starts at or before it
+    int lo = pg_lo, hi = pg_hi + 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (c.pages[vstreams[mid].page].slot_base <= s0) lo = mid; else hi = mid;
+    }
+    int pg = lo;
+    int p = vstreams[pg].page;
+    int64_t next_slot = pg + 1 < c.nd ? c.pages[vstreams[pg + 1].page].slot_base : n;
+    int64_t dense_base = c.state[p].dense_base, val_len = c.state[p].val_len;
+    const uint8_t *src = c.in + c.state[p].val_off;
+    T y[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      while (s0 + j >= next_slot && pg + 1 < c.nd) {   // (pages without slots are stepped over)
+        pg++;
+        p = vstreams[pg].page;
+        next_slot = pg + 1 < c.nd ? c.pages[vstreams[pg + 1].page].slot_base : n;
+        dense_base = c.state[p].dense_base; val_len = c.state[p].val_len;
+        src = c.in + c.state[p].val_off;
+      }
+      const int64_t off = (r - dense_base) * ESZ;
+      // (a page that is too short has failed; its slots only must not be read from beyond it)
+      y[j] = (vv[j] && off >= 0 && off + ESZ <= val_len) ? reinterpret_cast<const TU *>(src + off)->v : (T)0;
+      r += vv[j];
+    }
+    T *o = reinterpret_cast<T *>(out) + s0;
+    if (s0 + 4 <= n) {
+      if (ESZ == 4) {
+        V16Unaligned x = {{(uint32_t)y[0], (uint32_t)y[1], (uint32_t)y[2], (uint32_t)y[3]}};
+        *reinterpret_cast<V16Unaligned *>(o) = x;
+      } else {
+        V16Unaligned x0 = {{(uint32_t)y[0], (uint32_t)((uint64_t)y[0] >> 32), (uint32_t)y[1], (uint32_t)((uint64_t)y[1] >> 32)}};
+        V16Unaligned x1 = {{(uint32_t)y[2], (uint32_t)((uint64_t)y[2] >> 32), (uint32_t)y[3], (uint32_t)((uint64_t)y[3] >> 32)}};
+        reinterpret_cast<V16Unaligned *>(o)[0] = x0;
+        reinterpret_cast<V16Unaligned *>(o)[1] = x1;
+      }
+    } else for (int j = 0; s0 + j < n; j++) o[j] = y[j];
+  }
+}
+
 // ---- row index: out[r] = slot of the r-th entry with repetition level 0 (layout/table.go:73-103 cuts rows there) ----
 __global__ __launch_bounds__(256) void k_row_starts(const int32_t *rep, int64_t n, const int64_t *partial, int64_t *out,
                                                     int64_t n_rows) {
@@ -417,6 +524,23 @@ hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, co
     hipLaunchKernelGGL(k_scatter_apply<8>, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch, dense, out, 8);
   else
     hipLaunchKernelGGL(k_scatter_apply<1>, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch, dense, out, c.elem_size);
+  return hipGetLastError();
+}
+
+// scratch: n_tiles + 1 ranks (int64) followed by n_tiles + 1 page indices (int32)
+hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, uint8_t *out, int64_t n_slots, int64_t *scratch,
+                                hipStream_t stream) {
+  if (n_slots <= 0 || c.nd <= 0) return hipSuccess;
+  const int n_tiles = (int)((n_slots + kScatterTile - 1) / kScatterTile);
+  int32_t *tile_page = reinterpret_cast<int32_t *>(scratch + n_tiles + 1);
+  const int n_thr = (n_tiles + 1 > c.nd ? n_tiles + 1 : c.nd);
+  hipLaunchKernelGGL(k_scatter_tile_pages, dim3((n_thr + 255) / 256), dim3(256), 0, stream, c, n_slots, n_tiles, tile_page);
+  hipLaunchKernelGGL(k_scatter_count, dim3(n_tiles), dim3(256), 0, stream, def_levels, n_slots, c.max_def, scratch);
+  hipLaunchKernelGGL(k_scatter_scan, dim3(1), dim3(1024), 0, stream, scratch, n_tiles);
+  if (c.elem_size == 4)
+    hipLaunchKernelGGL(k_scatter_apply_plain<4>, dim3(n_tiles), dim3(256), 0, stream, c, def_levels, n_slots, scratch, tile_page, out);
+  else
+    hipLaunchKernelGGL(k_scatter_apply_plain<8>, dim3(n_tiles), dim3(256), 0, stream, c, def_levels, n_slots, scratch, tile_page, out);
   return hipGetLastError();
 }
 

@@ -508,7 +508,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       HIP_TRY(from_heavy());
     }
   }
-  if (any_plain) {
+  // a nullable column of PLAIN pages only: the scatter takes the values from the pages
+  const bool plain_scatter = nullable && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_other &&
+                             col->physical_type != PQD_BOOLEAN && (esz == 4 || esz == 8) && std::getenv("PQD_NO_PLAIN_SCATTER") == nullptr;
+  if (any_plain && !plain_scatter) {
     if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
   }
@@ -533,8 +536,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   }
   if (nullable && slots > 0) {
     const int n_tiles = (int)((slots + 4095) / 4096);
-    if ((rc = h->scratch.ensure(8 * (size_t)n_tiles + 64))) return rc;
-    Prof pf(h, "k_scatter");
+    if ((rc = h->scratch.ensure(12 * (size_t)n_tiles + 64))) return rc;
+    Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
+    if (plain_scatter)
+      HIP_TRY(launch_scatter_plain(c, static_cast<const int32_t *>(h->def.p), static_cast<uint8_t *>(h->values.p), slots,
+                                   static_cast<int64_t *>(h->scratch.p), h->stream));
+    else
     HIP_TRY(launch_scatter_fixed(c, static_cast<const int32_t *>(h->def.p), static_cast<const uint8_t *>(h->dense.p),
                                  static_cast<uint8_t *>(h->values.p), slots, static_cast<int64_t *>(h->scratch.p), h->stream));
   }

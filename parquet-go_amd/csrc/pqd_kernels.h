@@ -40,6 +40,10 @@ hipError_t launch_row_starts(const int32_t *rep_levels, int64_t n_slots, int64_t
                              hipStream_t stream);
 hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, const uint8_t *dense, uint8_t *out,
                                 int64_t n_slots, int64_t *scratch, hipStream_t stream);
+// the same for a column whose data pages are all PLAIN with 4- or 8-byte values: reads the pages, no dense copy
+// (scratch: 12 bytes per 4096 slots + 64)
+hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, uint8_t *out, int64_t n_slots, int64_t *scratch,
+                                hipStream_t stream);
 
 // ---- k_delta.hip ----
 // one wavefront per page whose value encoding is `encoding`; elem_size 4 or 8; src_sel 1 continues at the end of

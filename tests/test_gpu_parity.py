@@ -350,6 +350,42 @@ def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
     check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
 
 
+@pytest.mark.parametrize("copy_first", ["", "1"])
+@pytest.mark.parametrize("ptype", [pg.INT32, pg.INT64, pg.FLOAT, pg.DOUBLE])
+def test_nullable_plain_scattered_from_the_pages(dec, oracle, ptype, copy_first, monkeypatch):
+    # nullable column, PLAIN pages only: the scatter reads the value sections of the pages (no dense copy): many small
+    # pages per 4096 slots, pages that are all null, pages without slots, a page boundary inside a thread's four
+    # slots; then the same chunk with one page's value section a few bytes short (binaryread.go:12-18: ReadFull fails)
+    if copy_first:
+        monkeypatch.setenv("PQD_NO_PLAIN_SCATTER", "1")
+    rng = np.random.default_rng(6100 + ptype)
+    esz = np.dtype(PHYS_DT[ptype]).itemsize
+    for max_def, max_rep in ((1, 0), (3, 1)):
+        cb = pg.ChunkBuilder(gap=int(rng.integers(0, 7)), lead=int(rng.integers(0, 3)))
+        sizes = [1, 2, 3, 0, 5, 4090, 0, 0, 7, 1021, 3000, 11, 13, 20000, 2, 4096, 1, 9001] + [int(x) for x in rng.integers(1, 40, 60)]
+        for k, n in enumerate(sizes):
+            dl, rl = _levels(rng, n, max_def, max_rep) if n else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+            if k % 5 == 4:
+                dl[:] = 0           # nothing but nulls
+            if k % 7 == 6:
+                dl[:] = max_def     # no nulls
+            nn = int((dl == max_def).sum())
+            body = rng.integers(0, 256, nn * esz, dtype=np.uint8).tobytes()
+            if k % 2:
+                cb.data_page_v2(pg.ENC_PLAIN, n, body, pg.hybrid_encode(rl, 1, rng) if max_rep else b"",
+                                pg.hybrid_encode(dl, int(max_def).bit_length(), rng))
+            else:
+                cb.data_page_v1(pg.ENC_PLAIN, n, body, pg.level_block_v1(rl, max_rep, rng) if max_rep else b"",
+                                pg.level_block_v1(dl, max_def, rng))
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def, max_rep)
+        assert o.status == 0 and o.n_nulls > 0
+        short = pages.copy()
+        short["length"][13] -= 3
+        g, o = check_same(dec, oracle, chunk, short, ptype, 0, max_def, max_rep)
+        assert o.status != 0 and o.bad_page == 13
+
+
 @pytest.mark.parametrize("ptype,dt", [(pg.FLOAT, np.float32), (pg.DOUBLE, np.float64)])
 def test_byte_stream_split(dec, oracle, ptype, dt):
     rng = np.random.default_rng(61 + ptype)
