@@ -429,6 +429,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     int64_t *lens64 = static_cast<int64_t *>(h->lens64.p);
     int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
     HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages leave zero lengths behind
+    // (a dictionary walk that fails part way leaves the remaining entries as they are: they must read as empty
+    //  strings, not as whatever the buffer held, because the data pages are still expanded through them)
+    if (dict_page >= 0) HIP_TRY(hipMemsetAsync(h->dict_pairs.p, 0, 8 * (size_t)dict_n + 64, h->stream));
     if (dict_page >= 0) { Prof pf(h, "k_plain_ba_walk(dict)"); HIP_TRY(launch_plain_ba_walk(c, dict_page, static_cast<uint64_t *>(h->dict_pairs.p), h->stream)); }
     if (any_dict_enc) {
       if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
@@ -510,7 +513,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   }
   // a nullable column of PLAIN pages only: the scatter takes the values from the pages
   const bool plain_scatter = nullable && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_other &&
-                             col->physical_type != PQD_BOOLEAN && (esz == 4 || esz == 8) && std::getenv("PQD_NO_PLAIN_SCATTER") == nullptr;
+                             (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
+                              col->physical_type == PQD_DOUBLE) && std::getenv("PQD_NO_PLAIN_SCATTER") == nullptr;
   if (any_plain && !plain_scatter) {
     if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }

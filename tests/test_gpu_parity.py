@@ -748,6 +748,28 @@ def test_byte_array_dictionary(dec, oracle):
     assert g.bytes.tobytes() == b"StudentName" * 100
 
 
+def test_byte_array_dictionary_page_announcing_more_entries_than_it_holds(dec, oracle):
+    # the dictionary page fails part way through (encodingread.go:98-125: EOF at the entry after the last one), the
+    # data pages are expanded all the same and use indices of entries that were never read: those must read as
+    # empty strings, whatever the work buffer held before; a larger dictionary first, so that the buffer is reused
+    rng = np.random.default_rng(71)
+    big = rand_strings(rng, 3000, 1, 30)
+    cb = pg.ChunkBuilder()
+    cb.dict_page(pg.plain_byte_array(big), len(big))
+    cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, 5000, pg.dict_indices_body(rng.integers(0, len(big), 5000), 12, rng, "bp"))
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    words = rand_strings(rng, 40, 0, 12)
+    for announced in (51, 64, 4000):
+        cb = pg.ChunkBuilder(lead=1)
+        cb.dict_page(pg.plain_byte_array(words), announced)
+        w = max(6, int(announced - 1).bit_length())
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, 4000, pg.dict_indices_body(rng.integers(0, announced, 4000), w, rng, "mixed"))
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+        assert o.status == oracle.EOF and o.bad_page == 0
+
+
 @pytest.mark.parametrize("trim", [False, True])
 def test_delta_length_byte_array(dec, oracle, trim):
     rng = np.random.default_rng(62)
