@@ -56,8 +56,8 @@ __global__ void k_page_setup(ChunkCtx c) {
   Stream *all[3] = {&rs, &ds, &vs};
   for (int i = 0; i < 3; i++) {
     Stream &s = *all[i];
-    const Stream old = c.streams[i * c.nd + d];  // host-filled: run_base, run_cap, tile_base
-    s = old;
+    const StreamSeed sd = c.seeds[i * c.nd + d];
+    s.run_base = sd.run_base; s.run_cap = sd.run_cap; s.tile_base = sd.tile_base; s.pad = 0;
     s.off = 0; s.len = 0; s.avail = 0; s.w = 0; s.cnt = 0; s.out_base = pi.slot_base;
     s.page = p; s.n_runs = 0; s.status = 0; s.decoded = 0;
   }

@@ -245,23 +245,23 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
 
   // ---- meta block: pages | state | streams | tile prefixes | totals | status ----
   const size_t n_streams = (size_t)3 * nd;
-  std::vector<Stream> h_streams(n_streams);
+  std::vector<StreamSeed> h_seeds(n_streams);
   std::vector<int32_t> tp_levels(2 * (size_t)nd + 1, 0), tp_dict((size_t)nd + 1, 0), tp_plain((size_t)nd + 1, 0);
   int64_t run_total = 0, tile_total = 0;
   {
-    std::memset(h_streams.data(), 0, n_streams * sizeof(Stream));
+    if (n_streams) std::memset(h_seeds.data(), 0, n_streams * sizeof(StreamSeed));
     int64_t t_lv = 0, t_dc = 0, t_pl = 0;
     for (int g = 0; g < 3; g++) {
       for (int p = 0; p < n_pages; p++) {
         const PageIn &pi = h->h_pages[(size_t)p];
         if (pi.data_idx < 0) continue;
         const int d = pi.data_idx;
-        Stream &s = h_streams[(size_t)g * nd + d];
+        StreamSeed &s = h_seeds[(size_t)g * nd + d];
         const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
         const bool want = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) || (g == 2 && is_dict_enc(pi.encoding));
         const int64_t tiles = want ? (nv + kTile - 1) / kTile : 0;
         const int64_t rcap = want ? std::min<int64_t>(nv, pi.body_len) + 2 : 0;
-        s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total; s.page = p;
+        s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total;
         run_total += rcap;
         tile_total += tiles + 1;
         if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
@@ -281,36 +281,36 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     tp_dict[(size_t)nd] = (int32_t)t_dc;
     tp_plain[(size_t)nd] = (int32_t)t_pl;
   }
+  // uploaded: pages | seeds | tile prefixes | tile -> stream maps; device only (k_page_setup fills them): state | streams
   const size_t off_pages = 0;
-  const size_t off_state = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
-  const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
-  const size_t off_tp_lv = align_up(off_streams + sizeof(Stream) * n_streams, 256);
+  const size_t off_seeds = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
+  const size_t off_tp_lv = align_up(off_seeds + sizeof(StreamSeed) * n_streams, 256);
   const size_t off_tp_dc = align_up(off_tp_lv + 4 * tp_levels.size(), 256);
   const size_t off_tp_pl = align_up(off_tp_dc + 4 * tp_dict.size(), 256);
-  // tile -> stream maps of the two hybrid expansions
-  std::vector<int32_t> ts_levels((size_t)tp_levels.back()), ts_dict((size_t)tp_dict.back());
-  for (size_t i = 0; i + 1 < tp_levels.size(); i++)
-    for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_levels[(size_t)t] = (int32_t)i;
-  for (size_t i = 0; i + 1 < tp_dict.size(); i++)
-    for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dict[(size_t)t] = (int32_t)i;
   const size_t off_ts_lv = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
-  const size_t off_ts_dc = align_up(off_ts_lv + 4 * ts_levels.size(), 256);
-  const size_t meta_bytes = align_up(off_ts_dc + 4 * ts_dict.size(), 256);
+  const size_t off_ts_dc = align_up(off_ts_lv + 4 * (size_t)tp_levels.back(), 256);
+  const size_t upload_bytes = align_up(off_ts_dc + 4 * (size_t)tp_dict.back(), 256);
+  const size_t off_state = upload_bytes;
+  const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
+  const size_t meta_bytes = align_up(off_streams + sizeof(Stream) * n_streams, 256);
   int rc;
-  if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(meta_bytes))) return rc;
+  if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(upload_bytes))) return rc;
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
   {
     uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
-    std::memset(m, 0, meta_bytes);
     std::memcpy(m + off_pages, h->h_pages.data(), sizeof(PageIn) * (size_t)n_pages);
-    std::memcpy(m + off_streams, h_streams.data(), sizeof(Stream) * n_streams);
+    if (n_streams) std::memcpy(m + off_seeds, h_seeds.data(), sizeof(StreamSeed) * n_streams);
     std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
     std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
     std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
-    if (!ts_levels.empty()) std::memcpy(m + off_ts_lv, ts_levels.data(), 4 * ts_levels.size());
-    if (!ts_dict.empty()) std::memcpy(m + off_ts_dc, ts_dict.data(), 4 * ts_dict.size());
+    // tile -> stream maps of the two hybrid expansions, written in place
+    int32_t *ts_lv = reinterpret_cast<int32_t *>(m + off_ts_lv), *ts_dc = reinterpret_cast<int32_t *>(m + off_ts_dc);
+    for (size_t i = 0; i + 1 < tp_levels.size(); i++)
+      for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_lv[t] = (int32_t)i;
+    for (size_t i = 0; i + 1 < tp_dict.size(); i++)
+      for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
   }
-  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, meta_bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
 
   // ---- workspaces and outputs ----
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
@@ -347,6 +347,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   c.pages = reinterpret_cast<const PageIn *>(mb + off_pages);
   c.state = reinterpret_cast<PageState *>(mb + off_state);
   c.streams = reinterpret_cast<Stream *>(mb + off_streams);
+  c.seeds = reinterpret_cast<const StreamSeed *>(mb + off_seeds);
   c.runs = static_cast<RunEntry *>(h->runs.p);
   c.tile_run = static_cast<int32_t *>(h->tile_run.p);
   c.n_pages = n_pages; c.nd = nd; c.max_def = col->max_def; c.max_rep = col->max_rep;

@@ -55,6 +55,13 @@ struct Stream {
   int64_t decoded;   // values the whole stream holds (saturating)
 };
 
+// What the host knows about a stream before the page bodies are looked at; k_page_setup builds the Stream from it.
+struct StreamSeed {
+  int64_t run_base;
+  int32_t run_cap;
+  int32_t tile_base;
+};
+
 // Run-table entry: x = out_start | (bit_packed << 31); y = RLE value, or byte offset of the packed
 // payload inside the stream; z = work items of all earlier runs of the stream, an item being up to eight
 // consecutive values of one run (a run of n values has ceil(n / 8) items; a bit-packed item is one group of
@@ -91,6 +98,7 @@ struct ChunkCtx {
   const PageIn *pages;
   PageState *state;
   Stream *streams;       // [rep x nd | def x nd | values x nd]
+  const StreamSeed *seeds; // same order, host-filled
   RunEntry *runs;
   int32_t *tile_run;
   int32_t n_pages;
