@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
   d.t0 = k * kTile;
   d.page = sp->page;
   d.pad = 0;
-  if (sp->status != 0 || d.t0 >= cnt) {
+  if (sp->status != 0 || sp->direct || d.t0 >= cnt) {
     d.in_off = 0; d.out_elem = 0; d.run0 = 0; d.item_lo = 0; d.n_items = 0; d.t1 = d.t0; d.org = 0; d.span = 0; d.nr = 0;
     d.avail = 0; d.w = 0;
     a.descs[tile] = d;

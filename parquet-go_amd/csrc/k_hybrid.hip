@@ -59,7 +59,7 @@ __global__ void k_page_setup(ChunkCtx c) {
     const StreamSeed sd = c.seeds[i * c.nd + d];
     s.run_base = sd.run_base; s.run_cap = sd.run_cap; s.tile_base = sd.tile_base; s.pad = 0;
     s.off = 0; s.len = 0; s.avail = 0; s.w = 0; s.cnt = 0; s.out_base = pi.slot_base;
-    s.page = p; s.n_runs = 0; s.status = 0; s.decoded = 0;
+    s.page = p; s.n_runs = 0; s.status = 0; s.decoded = 0; s.direct = 0; s.spare = 0;
   }
   int64_t pos = pi.body_off, end = pi.body_off + pi.body_len;
   const int64_t nv = pi.num_values;
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
   Stream *sp = &c.streams[s0 + blockIdx.x];
   const int status_in = sp->status;
   const int cnt = sp->cnt;
+  if (sp->direct) return;  // already expanded
   if (status_in != 0 || cnt <= 0) {
     if (lane == 0) { sp->n_runs = 0; sp->decoded = 0; }
     return;
@@ -733,6 +734,92 @@ __global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c) {
       vs->status = st;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rle_only_pages: dictionary-index streams that consist of nothing but RLE runs with a one-byte header - what the
+// reference's own writer produces for every dictionary page (layout/dictpage.go:155-158 -> encodingwrite.go:149-214:
+// width 32, one run per change of value, so 5 bytes for every value or two).  A run table of 16 bytes per run and an
+// expansion by work items would move several times the bytes of the page; instead one workgroup per page checks
+// that every header, at its fixed stride, has that shape (and that the runs hold enough values), and then writes the
+// looked-up values straight to the output: run k starts at the sum of the counts before it.  Anything else - another
+// header anywhere, a stream that does not end on a run boundary, zero fill, too few values - leaves the stream to the
+// general path untouched, so the reference's behaviour on odd input stays in one place.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDirectMaxLen = 64 * 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict, int dict_n, T *__restrict__ values_out) {
+  __shared__ uint32_t s_sum[4];
+  __shared__ int s_flag[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  Stream *sp = &c.streams[2 * c.nd + blockIdx.x];
+  const int w = sp->w, cnt = sp->cnt, len = sp->len;
+  if (sp->status != 0 || cnt <= 0 || w <= 0 || w > 32 || len != sp->avail || len <= 0 || len > kDirectMaxLen) return;
+  const uint32_t nb = (uint32_t)(w + 7) / 8, stride = 1u + nb;
+  if ((uint32_t)len % stride) return;
+  const int n_runs = (int)((uint32_t)len / stride);
+  const uint32_t vmask = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+  const uint8_t *src = c.in + sp->off;
+  // every header: one byte, RLE, not empty; and the values they announce
+  uint32_t total = 0;
+  int bad = 0;
+  for (int k = tid; k < n_runs; k += 256) {
+    const uint32_t hb = src[(uint32_t)k * stride];
+    bad |= (hb & 0x81u) != 0u || hb == 0u;
+    total += hb >> 1;
+  }
+  for (int o = 32; o > 0; o >>= 1) { total += __shfl_down(total, o); bad |= __shfl_down(bad, o); }
+  if (lane == 0) { s_sum[wv] = total; s_flag[wv] = bad; }
+  __syncthreads();
+  total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  bad = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
+  if (bad || total < (uint32_t)cnt) return;
+  T *out = values_out + sp->out_base;
+  uint32_t carry = 0;
+  int bad_index = 0;
+  for (int k0 = 0; k0 < n_runs && carry < (uint32_t)cnt; k0 += 256) {
+    const int k = k0 + tid;
+    uint32_t n = 0, val = 0;
+    if (k < n_runs) {
+      const uint8_t *r = src + (uint32_t)k * stride;
+      n = (uint32_t)r[0] >> 1;
+      val = ((uint32_t)r[1] | (nb > 1 ? (uint32_t)r[2] << 8 : 0u) | (nb > 2 ? (uint32_t)r[3] << 16 : 0u) | (nb > 3 ? (uint32_t)r[4] << 24 : 0u)) & vmask;
+    }
+    uint32_t incl = n;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    __syncthreads();  // the previous round's sums have been read
+    if (lane == 63) s_sum[wv] = incl;
+    __syncthreads();
+    uint32_t before = carry, round = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { if (q < wv) before += s_sum[q]; round += s_sum[q]; }
+    const uint32_t start = before + incl - n;
+    if (n > 0 && start < (uint32_t)cnt) {
+      uint32_t idx = val;
+      if (idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
+      const T v = dict_n > 0 ? dict[idx] : T(0);
+      const uint32_t end = start + n < (uint32_t)cnt ? start + n : (uint32_t)cnt;
+      for (uint32_t j = start; j < end; j++) out[j] = v;
+    }
+    carry += round;
+  }
+  if (__syncthreads_or(bad_index)) { if (tid == 0) set_status(&c.state[sp->page].status, PQD_ERR_MALFORMED); }
+  if (tid == 0) { sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)total; }
+}
+
+hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  if (c.elem_size == 4)
+    hipLaunchKernelGGL(k_rle_only_pages<uint32_t>, dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint32_t *>(dict), dict_n,
+                       reinterpret_cast<uint32_t *>(values_out));
+  else if (c.elem_size == 8)
+    hipLaunchKernelGGL(k_rle_only_pages<uint64_t>, dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint64_t *>(dict), dict_n,
+                       reinterpret_cast<uint64_t *>(values_out));
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
   Stream *sp = &c.streams[s0 + blockIdx.x];
   const int status_in = sp->status;
   const int cnt = sp->cnt;
+  if (sp->direct) return;  // already expanded (k_rle_only_pages)
   if (status_in != 0 || cnt <= 0) {
     if (tid == 0) { sp->n_runs = 0; sp->decoded = 0; }
     return;

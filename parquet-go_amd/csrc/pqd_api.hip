@@ -395,6 +395,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   // indices of low-cardinality columns have them too (PQD_JUMP=0|1 pins the choice; the variant costs 6 KiB of LDS
   // per stream, which the benchmark's crowd of seven chunks does not miss: 5.41 against 5.52 ms per step).
   bool jump_levels = true, jump_dict = true;
+  // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first (PQD_DIRECT_RLE=0|1)
+  bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;
+  if (const char *fd = std::getenv("PQD_DIRECT_RLE")) direct_rle = fd[0] == '1';
   if (const char *fj = std::getenv("PQD_JUMP")) jump_levels = jump_dict = fj[0] == '1';
 
   // hand-over of the dictionary expansion to the device's shared stream and back
@@ -438,6 +441,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     if (any_dict_enc) {
       if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
       else {
+        if (direct_rle) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c8, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n, reinterpret_cast<uint8_t *>(pairs), h->stream)); }
         { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
         HIP_TRY(to_heavy());
         { Prof pf(h, "k_hybrid_expand<dict>", heavy);
@@ -505,6 +509,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (any_dict_enc) {
     if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
     else {
+      if (direct_rle && (esz == 4 || esz == 8)) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->stream)); }
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);

@@ -53,6 +53,8 @@ struct Stream {
   int32_t status;    // written by setup / prescan
   int32_t pad;
   int64_t decoded;   // values the whole stream holds (saturating)
+  int32_t direct;    // the stream was expanded by k_rle_only_pages: no run table, no tiles
+  int32_t spare;
 };
 
 // What the host knows about a stream before the page bodies are looked at; k_page_setup builds the Stream from it.

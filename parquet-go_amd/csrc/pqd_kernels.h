@@ -12,6 +12,9 @@ hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream);
 // wide: one 576-thread workgroup per stream (few long streams) instead of one wavefront per stream
 // jump: the wavefront variant that also resolves spans of short runs at once (4 KiB more LDS per stream)
 hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bool jump, hipStream_t stream);
+// dictionary-index streams made of one-byte-header RLE runs only (pages of up to 64 KiB, 4- or 8-byte entries) are
+// expanded straight from the page; they are marked and skipped by the prescan and the tile expansion
+hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream);
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)

@@ -138,6 +138,64 @@ def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
     check_same(dec, oracle, chunk, pages, pg.INT32)
 
 
+@pytest.mark.parametrize("direct", ["1", "0"])
+@pytest.mark.parametrize("ptype,w", [(pg.INT32, 32), (pg.INT64, 32), (pg.INT32, 9), (pg.DOUBLE, 1), (pg.BYTE_ARRAY, 32), (pg.INT96, 32),
+                                     (pg.BYTE_ARRAY, 7)])
+def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, direct, monkeypatch):
+    # index streams of one-byte-header RLE runs only (WriteRLE, encodingwrite.go:149-214) skip the run table when the
+    # entries are 4 or 8 bytes wide; with nulls; a count that ends inside a run; and the pages that must stay on the
+    # general path: a trailing byte, an empty run, a two-byte header, a bit-packed run, too few values; an index
+    # beyond the dictionary
+    monkeypatch.setenv("PQD_DIRECT_RLE", direct)
+    rng = np.random.default_rng(8100 + w + ptype)
+    nd = min(1 << w, 300)
+    nb = (w + 7) // 8
+
+    def runs(n_values, max_run=3, hi=None):
+        out, vals = bytearray(), []
+        while len(vals) < n_values:
+            c, v = int(rng.integers(1, max_run + 1)), int(rng.integers(0, hi or nd))
+            if hi and not vals:
+                v = hi - 1
+            out += bytes([c << 1]) + v.to_bytes(4, "little")[:nb]
+            vals += [v] * c
+        return bytes(out), len(vals)
+
+    def builder():
+        cb = pg.ChunkBuilder(gap=int(rng.integers(0, 5)), lead=int(rng.integers(0, 3)))
+        if ptype == pg.BYTE_ARRAY:
+            cb.dict_page(pg.plain_byte_array(rand_strings(rng, nd, 0, 20)), nd)
+        else:
+            cb.dict_page(rand_dict(rng, ptype, nd), nd)
+        return cb
+
+    def page(cb, n, max_def, tail=b"", short=0, max_run=3, hi=None):
+        dl = rng.integers(0, max_def + 1, n) if max_def else np.zeros(n, np.int64)
+        nn = int((dl == max_def).sum())
+        body, have = runs(max(nn - short, 1) if short else nn + int(rng.integers(0, 3)), max_run, hi)
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([w]) + body + tail, b"", pg.level_block_v1(dl, max_def, rng) if max_def else b"")
+
+    for max_def in (0, 2):
+        cb = builder()
+        for k, n in enumerate([1, 2, 300, 2048, 2048, 1500, 7000]):
+            page(cb, n, max_def, max_run=63 if k == 6 else 3)
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def, 0)
+        assert o.status == 0
+        # pages that stay on the general path, each behind two good ones: a trailing byte, an empty run, a two-byte
+        # header, a bit-packed run, too few values; and an index beyond the dictionary
+        for tail, short, hi in ((b"\x00", 0, None), (b"\x00" + bytes(nb), 0, None), (pg.varint(100 << 1) + bytes(nb), 0, None),
+                                (pg.varint(3) + pg.bitpack([0] * 8, w), 0, None), (b"", 5, None), (b"", 0, nd + 1)):
+            cb = builder()
+            page(cb, 500, max_def)
+            page(cb, 40, max_def)
+            page(cb, 600, max_def, tail, short, 3, hi)
+            chunk, pages = cb.finish()
+            g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def, 0)
+            if hi and nd < (1 << (8 * nb)):
+                assert o.status == oracle.PANIC and o.bad_page == 3
+
+
 @pytest.mark.parametrize("variant", ["wave", "wide"])
 @pytest.mark.parametrize("w", [1, 2, 7, 8, 9, 16, 20, 32])
 def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant, monkeypatch):
