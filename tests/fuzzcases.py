@@ -85,7 +85,8 @@ def base_case(kind, rng):
         if kind == "dict_short":
             idx = np.repeat(rng.integers(0, nd, nn // 3 + 1), rng.integers(1, 6, nn // 3 + 1))[:nn]
             idx = np.concatenate([idx, rng.integers(0, nd, nn - len(idx))])
-            body, enc = bytes([w]) + pg.hybrid_encode(idx, w, rng, "mixed", mg), pg.ENC_RLE_DICTIONARY
+            # (every other page the way the reference's writer lays it out: RLE runs only)
+            body, enc = bytes([w]) + pg.hybrid_encode(idx, w, rng, "rle" if rng.integers(0, 2) else "mixed", mg), pg.ENC_RLE_DICTIONARY
         elif kind == "dict32":
             body, enc = pg.dict_indices_body(rng.integers(0, nd, nn), w, rng), pg.ENC_RLE_DICTIONARY
         elif kind == "dict_ba":
