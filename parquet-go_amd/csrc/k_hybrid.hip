@@ -748,12 +748,18 @@ __global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kDirectMaxLen = 64 * 1024;
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict, int dict_n, T *__restrict__ values_out) {
+// kLevels: the same for repetition / definition level streams (the reference writes those with WriteRLE too,
+// layout/page.go:234-238); the values are the levels themselves, and the nulls (definition level below the maximum)
+// or row starts (repetition level 0) are counted into the page state as the tile expansion would.
+template <typename T, bool kLevels>
+__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict, int dict_n, T *__restrict__ values_out,
+                                                        int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
   __shared__ uint32_t s_sum[4];
   __shared__ int s_flag[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  Stream *sp = &c.streams[2 * c.nd + blockIdx.x];
+  const int si = kLevels ? (int)blockIdx.x : 2 * c.nd + (int)blockIdx.x;
+  const bool is_def = kLevels && si >= c.nd;
+  Stream *sp = &c.streams[si];
   const int w = sp->w, cnt = sp->cnt, len = sp->len;
   if (sp->status != 0 || cnt <= 0 || w <= 0 || w > 32 || len != sp->avail || len <= 0 || len > kDirectMaxLen) return;
   const uint32_t nb = (uint32_t)(w + 7) / 8, stride = 1u + nb;
@@ -775,9 +781,10 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
   bad = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
   if (bad || total < (uint32_t)cnt) return;
-  T *out = values_out + sp->out_base;
+  T *out = kLevels ? reinterpret_cast<T *>(is_def ? def_out : rep_out) + sp->out_base : values_out + sp->out_base;
+  const uint32_t flag_val = is_def ? (uint32_t)c.max_def : 0u;
   uint32_t carry = 0;
-  int bad_index = 0;
+  int bad_index = 0, n_flag = 0;
   for (int k0 = 0; k0 < n_runs && carry < (uint32_t)cnt; k0 += 256) {
     const int k = k0 + tid;
     uint32_t n = 0, val = 0;
@@ -799,13 +806,23 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
     for (int q = 0; q < 4; q++) { if (q < wv) before += s_sum[q]; round += s_sum[q]; }
     const uint32_t start = before + incl - n;
     if (n > 0 && start < (uint32_t)cnt) {
-      uint32_t idx = val;
-      if (idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
-      const T v = dict_n > 0 ? dict[idx] : T(0);
       const uint32_t end = start + n < (uint32_t)cnt ? start + n : (uint32_t)cnt;
+      T v;
+      if (kLevels) {
+        v = (T)val;
+        if (is_def ? val != flag_val : val == flag_val) n_flag += (int)(end - start);
+      } else {
+        uint32_t idx = val;
+        if (idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
+        v = dict_n > 0 ? dict[idx] : T(0);
+      }
       for (uint32_t j = start; j < end; j++) out[j] = v;
     }
     carry += round;
+  }
+  if (kLevels) {
+    for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
+    if (lane == 0 && n_flag) atomicAdd(is_def ? &c.state[sp->page].n_nulls : &c.state[sp->page].n_rows, n_flag);
   }
   if (__syncthreads_or(bad_index)) { if (tid == 0) set_status(&c.state[sp->page].status, PQD_ERR_MALFORMED); }
   if (tid == 0) { sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)total; }
@@ -814,11 +831,18 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
 hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (c.elem_size == 4)
-    hipLaunchKernelGGL(k_rle_only_pages<uint32_t>, dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint32_t *>(dict), dict_n,
-                       reinterpret_cast<uint32_t *>(values_out));
+    hipLaunchKernelGGL((k_rle_only_pages<uint32_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint32_t *>(dict), dict_n,
+                       reinterpret_cast<uint32_t *>(values_out), (int32_t *)nullptr, (int32_t *)nullptr);
   else if (c.elem_size == 8)
-    hipLaunchKernelGGL(k_rle_only_pages<uint64_t>, dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint64_t *>(dict), dict_n,
-                       reinterpret_cast<uint64_t *>(values_out));
+    hipLaunchKernelGGL((k_rle_only_pages<uint64_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint64_t *>(dict), dict_n,
+                       reinterpret_cast<uint64_t *>(values_out), (int32_t *)nullptr, (int32_t *)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *def_out, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_rle_only_pages<int32_t, true>), dim3(2 * c.nd), dim3(256), 0, stream, c, (const int32_t *)nullptr, 0, (int32_t *)nullptr,
+                     rep_out, def_out);
   return hipGetLastError();
 }
 

@@ -418,6 +418,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (n_pages > 0) {
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
+      if (direct_rle) { Prof pf(h, "k_rle_only_pages(levels)"); HIP_TRY(launch_rle_only_levels(c, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
       { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, jump_levels, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
         HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }

@@ -15,6 +15,8 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bo
 // dictionary-index streams made of one-byte-header RLE runs only (pages of up to 64 KiB, 4- or 8-byte entries) are
 // expanded straight from the page; they are marked and skipped by the prescan and the tile expansion
 hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream);
+// the same for the repetition / definition level streams (streams [0, 2 nd)); counts nulls and row starts per page
+hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *def_out, hipStream_t stream);
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)

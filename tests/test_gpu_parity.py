@@ -169,18 +169,24 @@ def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, d
             cb.dict_page(rand_dict(rng, ptype, nd), nd)
         return cb
 
-    def page(cb, n, max_def, tail=b"", short=0, max_run=3, hi=None):
+    def page(cb, n, levels, tail=b"", short=0, max_run=3, hi=None):
+        max_def, max_rep, style = levels
         dl = rng.integers(0, max_def + 1, n) if max_def else np.zeros(n, np.int64)
+        rl = rng.integers(0, max_rep + 1, n) if max_rep else np.zeros(n, np.int64)
+        rl[0] = 0
         nn = int((dl == max_def).sum())
         body, have = runs(max(nn - short, 1) if short else nn + int(rng.integers(0, 3)), max_run, hi)
-        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([w]) + body + tail, b"", pg.level_block_v1(dl, max_def, rng) if max_def else b"")
+        cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([w]) + body + tail,
+                        pg.level_block_v1(rl, max_rep, rng, style) if max_rep else b"",
+                        pg.level_block_v1(dl, max_def, rng, style) if max_def else b"")
 
-    for max_def in (0, 2):
+    # (level streams written as RLE runs only, layout/page.go:234-238, take the same route when every run is short)
+    for max_def in ((0, 0, "mixed"), (2, 0, "rle"), (2, 1, "rle"), (3, 1, "mixed")):
         cb = builder()
         for k, n in enumerate([1, 2, 300, 2048, 2048, 1500, 7000]):
             page(cb, n, max_def, max_run=63 if k == 6 else 3)
         chunk, pages = cb.finish()
-        g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def, 0)
+        g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def[0], max_def[1])
         assert o.status == 0
         # pages that stay on the general path, each behind two good ones: a trailing byte, an empty run, a two-byte
         # header, a bit-packed run, too few values; and an index beyond the dictionary
@@ -191,7 +197,7 @@ def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, d
             page(cb, 40, max_def)
             page(cb, 600, max_def, tail, short, 3, hi)
             chunk, pages = cb.finish()
-            g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def, 0)
+            g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def[0], max_def[1])
             if hi and nd < (1 << (8 * nb)):
                 assert o.status == oracle.PANIC and o.bad_page == 3
 
