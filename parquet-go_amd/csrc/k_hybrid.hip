@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_pages_count(ChunkCtx c) {
 }
 
 __global__ __launch_bounds__(1024) void k_pages_finalize(ChunkCtx c, int64_t *totals) {
-  constexpr int kPer = 4;                       // consecutive pages per thread and round: their loads overlap
+  constexpr int kPer = 16;                      // consecutive pages per thread and round: their loads overlap
   __shared__ int64_t s_wave[16];
   __shared__ unsigned long long s_tot[4];       // running totals: slots, values, nulls, rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
