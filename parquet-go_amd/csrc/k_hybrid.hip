@@ -317,10 +317,11 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
           // of headers inside a span of kSpan bytes is resolved by all lanes together instead of one header at a
           // time.  Every lane works out, for each of its 32 byte positions, where the next header would be if a
           // header started there (1- or 2-byte headers of non-empty runs that end inside the stream; any other
-          // position is its own successor and ends the chain).  Squaring that successor table log2(runs) times
-          // while marking the successors of marked positions, starting from the one position known to be a header,
-          // marks exactly the headers the one-at-a-time walk would visit.  They are then recorded 64 per step with
-          // prefix sums, cut at the run that completes the count.
+          // position is its own successor and ends the chain).  Starting from the one position known to be a header,
+          // the list of visited headers doubles in length with every squaring of that successor table (the header
+          // len + i runs on is the len-th successor of the header i runs on), so log2(runs) rounds list exactly the
+          // headers the one-at-a-time walk would visit, in order.  They are then recorded 64 per step with prefix
+          // sums, cut at the run that completes the count.
           while (q < lim && o32 < ucnt) {
             const uint32_t q0 = q;
             const uint32_t pl = q0 + 32u * (uint32_t)lane;  // the first of this lane's positions
