@@ -32,7 +32,9 @@ extern "C" {
 #define PQD_ERR_MALFORMED (-3)             /* input on which the reference panics (short stream, index out of range, ...) */
 #define PQD_ERR_UNSUPPORTED_ENCODING (-4)  /* "Unsupported Encoding method ..." / "Unknown Encoding method", layout/page.go:671,716 */
 #define PQD_ERR_UNSUPPORTED_PAGE_TYPE (-5) /* "Unsupported page type: INDEX_PAGE", layout/page.go:813-814,934 */
-#define PQD_ERR_UNSUPPORTED_TYPE (-6)      /* physical type / encoding combination outside this build */
+#define PQD_ERR_UNSUPPORTED_TYPE (-6)      /* physical type / encoding combination without a typed result: Encoding_RLE
+                                              values of a column that is not BOOLEAN, INT32 or INT64 (the reference hands
+                                              out int64 numbers in place of such values, layout/page.go:657-667) */
 #define PQD_ERR_BIT_WIDTH (-7)             /* bit width the kernels do not implement (> 32 hybrid, > 64 delta) */
 #define PQD_ERR_INVALID_ARG (-8)
 #define PQD_ERR_HIP (-9)                   /* a HIP runtime call failed; see pqd_last_error() */
@@ -45,6 +47,8 @@ extern "C" {
                                               v2 level sections that contradict the column's maximum levels (the reference
                                               reads the next section in their place, layout/page.go:736-773), length or
                                               prefix streams of byte-array pages announcing more values than the page holds */
+#define PQD_ERR_CAPACITY (-14)             /* an output array of the caller is too small (pqd_scan_pages: more pages than `cap`
+                                              descriptors); nothing is wrong with the input: grow the array and call again */
 
 /* parquet.Type (parquet/parquet.go:28-37) */
 enum { PQD_BOOLEAN = 0, PQD_INT32 = 1, PQD_INT64 = 2, PQD_INT96 = 3, PQD_FLOAT = 4, PQD_DOUBLE = 5,
@@ -123,10 +127,25 @@ int pqd_handle_create(int device, void *stream, pqd_handle **out);
 int pqd_handle_destroy(pqd_handle *h);
 int pqd_set_profiling(pqd_handle *h, int on);
 
+/* Kernel-variant choices of a handle.  Results never depend on them; tests pin each variant with them.  value -1
+ * returns a choice to the library.  New handles start from the environment (read once per process):
+ * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1. */
+enum {
+  PQD_OPT_PRESCAN = 0,        /* run-header walk: 0 a wavefront per stream, 1 a workgroup per stream */
+  PQD_OPT_DIRECT_RLE = 1,     /* 0 / 1: expansion of RLE-only pages straight from the page */
+  PQD_OPT_JUMP = 2,           /* 0 / 1: spans of short runs resolved by all lanes at once */
+  PQD_OPT_PLAIN_SCATTER = 3,  /* 0 / 1: nullable PLAIN columns scattered straight from the pages */
+  PQD_OPT_SPLIT = 4,          /* 0 / 1: head of a mid-size dictionary kept in LDS */
+  PQD_OPT_POISON = 5,         /* 1: every work and output buffer is filled with 0xFF before each call (debugging aid) */
+  PQD_OPT_COUNT = 6
+};
+int pqd_set_option(pqd_handle *h, int option, int value);
+
 /* Host-side page walk over the bytes of one column chunk: parses each thrift compact PageHeader and
  * fills one descriptor per page until total_values level slots are covered (the loop condition of
  * ColumnBufferType.ReadPage, reader/columnbuffer.go:106) or the buffer ends.
- * Replaces layout.ReadPageHeader, layout/page.go:625-630. */
+ * Returns PQD_ERR_CAPACITY (with *n_out = cap) when the chunk holds more pages than `cap`: call again with a larger
+ * array.  Replaces layout.ReadPageHeader, layout/page.go:625-630. */
 int pqd_scan_pages(const uint8_t *chunk, size_t len, int64_t total_values, pqd_page_desc *out, int32_t cap,
                    int32_t *n_out);
 
@@ -170,10 +189,14 @@ int pqd_footer_chunk(const pqd_footer *f, int32_t i, pqd_chunk_desc *out);
 int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages,
                      int32_t n_pages, const pqd_column_desc *col);
 
-/* Page-locked input buffer of the handle, at least len bytes: a caller that reads the chunk from the file straight
+/* A handle runs one call at a time: a decode call on a handle whose previous call has not been waited for first
+ * waits for it (its result is dropped).  Use several handles to keep several calls in flight.
+ *
+ * Page-locked input buffer of the handle, at least len bytes: a caller that reads the chunk from the file straight
  * into it (the io.ReadFull of reader/columnbuffer.go:105-156's callers) and passes the same pointer to
- * pqd_decode_chunk / pqd_decode_levels saves the copy into staging.  Valid until the next pqd_input_buffer call
- * with a larger len; write to it only after pqd_wait of the handle's previous decode. */
+ * pqd_decode_chunk / pqd_decode_levels saves the copy into staging.  A handle has two such buffers that take turns:
+ * the pointer is valid until the second next pqd_input_buffer call, and may be filled while the decode of the
+ * buffer handed out before it is still in flight. */
 int pqd_input_buffer(pqd_handle *h, size_t len, uint8_t **buf);
 
 /* Same, chunk bytes already in device memory.  d_chunk must be 16-byte aligned and readable up to
@@ -190,7 +213,23 @@ int pqd_decode_levels(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd
 int pqd_decode_levels_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages,
                              int32_t n_pages, const pqd_column_desc *col);
 
-/* Wait for the handle's stream and collect status and totals. */
+/* Several column chunks of one leaf column in one call (consecutive row groups: what ColumnBufferType.ReadRows pulls
+ * through NextRowGroup + ReadPage until it has its rows, reader/columnbuffer.go:53-103, :232-262).  chunks[k] / lens[k]
+ * are the bytes of chunk k, `pages` holds the descriptors of all chunks back to back (offsets relative to their own
+ * chunk), pages_per_chunk[k] says how many belong to chunk k.  One meta block, one kernel sequence; the result is the
+ * table of all chunks merged in order, pqd_page_counts reports every page.  A dictionary page serves the data pages
+ * after it up to the next dictionary page or the end of its chunk.  flags: PQD_LEVELS_ONLY = levels and counts only.
+ * The _device variant takes 16-byte aligned device pointers, each readable up to lens[k] rounded up to 16. */
+#define PQD_LEVELS_ONLY 1
+int pqd_decode_chunks(pqd_handle *h, int32_t n_chunks, const uint8_t *const *chunks, const size_t *lens,
+                      const pqd_page_desc *pages, const int32_t *pages_per_chunk, const pqd_column_desc *col, int32_t flags);
+int pqd_decode_chunks_device(pqd_handle *h, int32_t n_chunks, const void *const *d_chunks, const size_t *lens,
+                             const pqd_page_desc *pages, const int32_t *pages_per_chunk, const pqd_column_desc *col,
+                             int32_t flags);
+
+/* Wait for the handle's stream and collect status and totals.  Decode calls only enqueue work (BYTE_ARRAY columns
+ * included: their byte output is sized from the page bytes, and a call whose strings need more - dictionary or
+ * prefix expansion - has its copies redone here into a larger buffer). */
 int pqd_wait(pqd_handle *h, pqd_chunk_result *res);
 
 /* Device pointers of the last decoded chunk (after pqd_wait). */

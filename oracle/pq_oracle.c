@@ -590,7 +590,19 @@ static int read_data_page(const uint8_t *body, int64_t body_len, const orc_page_
       if (t->def[base + i] == col->max_def) {
         if (j >= avail) { rc = ORC_PANIC; goto done; } /* values[j] out of range */
         if (is_idx) {
-          if (!is_dict_enc) { rc = ORC_UNSUPPORTED; goto done; } /* RLE-encoded values are not modelled */
+          if (!is_dict_enc) {
+            /* Encoding_RLE values (:657-667): the numbers are the values, int32(value) for INT32.  The typed image
+             * exists for BOOLEAN (low byte), INT32 and INT64; for any other type the reference holds int64 numbers
+             * where values of that type belong, which has no typed counterpart. */
+            int64_t v = idx.v[j];
+            if (col->physical_type == ORC_BOOLEAN) { uint8_t b = (uint8_t)v; rc = col_push_fixed(&t->values, &b); }
+            else if (col->physical_type == ORC_INT32) { int32_t w = (int32_t)v; rc = col_push_fixed(&t->values, &w); }
+            else if (col->physical_type == ORC_INT64) rc = col_push_fixed(&t->values, &v);
+            else rc = ORC_UNSUPPORTED_TYPE;
+            if (rc) goto done;
+            j++;
+            continue;
+          }
           if (!dict) { rc = ORC_UNSUPPORTED; goto done; }        /* Decode() leaves raw indices: treated as an error */
           int64_t k = idx.v[j];
           if (k < 0 || k >= dict->n) { rc = ORC_PANIC; goto done; } /* dictPage.DataTable.Values[index] */

@@ -30,7 +30,8 @@ enum {
   ORC_UNEXPECTED_EOF = -2, /* io.ErrUnexpectedEOF */
   ORC_PANIC = -3,          /* slice/index out of range, division by zero, negative make(), endless loop */
   ORC_UNSUPPORTED = -4,    /* fmt.Errorf("Unsupported ...") / "Unknown ..." returns */
-  ORC_NOMEM = -5
+  ORC_NOMEM = -5,
+  ORC_UNSUPPORTED_TYPE = -6 /* a value encoding without a typed result for the column's type (stand-in of the checker) */
 };
 
 /* parquet enums (parquet/parquet.go:28-37, :345-355, :533-538) */

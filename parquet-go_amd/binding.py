@@ -23,8 +23,14 @@ EXPORTS = [
     "pqd_handle_destroy", "pqd_set_profiling", "pqd_scan_pages", "pqd_decode_chunk",
     "pqd_decode_chunk_device", "pqd_wait", "pqd_result_device", "pqd_copy_out", "pqd_page_counts",
     "pqd_kernel_times", "pqd_decode_levels", "pqd_decode_levels_device", "pqd_row_starts", "pqd_result_host",
-    "pqd_input_buffer",
+    "pqd_input_buffer", "pqd_set_option", "pqd_decode_chunks", "pqd_decode_chunks_device",
+    "pqd_footer_locate", "pqd_footer_parse", "pqd_footer_free", "pqd_footer_num_rows", "pqd_footer_num_row_groups",
+    "pqd_footer_num_leaves", "pqd_footer_num_chunks", "pqd_footer_leaf", "pqd_footer_chunk",
 ]
+
+OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON = range(6)
+LEVELS_ONLY = 1
+ERR_CAPACITY = -14
 
 
 class _ColDesc(C.Structure):
@@ -84,6 +90,9 @@ def lib():
         L.pqd_handle_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.pqd_handle_destroy.argtypes = [C.c_void_p]
         L.pqd_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.pqd_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for fn in (L.pqd_decode_chunks, L.pqd_decode_chunks_device):
+            fn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_ColDesc), C.c_int32]
         L.pqd_scan_pages.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.pqd_decode_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_chunk_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
@@ -122,14 +131,18 @@ def _check(rc):
 def scan_pages(chunk, total_values=-1, cap=None):
     """Host-side page-header walk -> structured array of page descriptors (PAGE_DESC_DTYPE)."""
     a = np.frombuffer(chunk, dtype=np.uint8) if not isinstance(chunk, np.ndarray) else np.ascontiguousarray(chunk, np.uint8)
-    cap = cap or max(16, a.size // 16 + 16)
-    out = np.zeros(cap, dtype=PAGE_DESC_DTYPE)
-    n = C.c_int32(0)
-    rc = lib().pqd_scan_pages(C.c_void_p(a.ctypes.data if a.size else None) if a.size else C.c_void_p(out.ctypes.data),
-                              a.size, total_values, C.c_void_p(out.ctypes.data), cap, C.byref(n))
-    if rc != 0:
-        raise DecodeError(rc, page=n.value)
-    return out[:n.value].copy()
+    cap = cap or 64
+    while True:
+        out = np.zeros(cap, dtype=PAGE_DESC_DTYPE)
+        n = C.c_int32(0)
+        rc = lib().pqd_scan_pages(C.c_void_p(a.ctypes.data if a.size else None) if a.size else C.c_void_p(out.ctypes.data),
+                                  a.size, total_values, C.c_void_p(out.ctypes.data), cap, C.byref(n))
+        if rc == ERR_CAPACITY:      # more pages than descriptors: grow and walk again
+            cap *= 4
+            continue
+        if rc != 0:
+            raise DecodeError(rc, page=n.value)
+        return out[:n.value].copy()
 
 
 def read_footer(file_bytes):
@@ -203,6 +216,38 @@ class Decoder:
     @staticmethod
     def _col(physical_type, type_length, max_def, max_rep):
         return _ColDesc(physical_type, type_length, max_def, max_rep)
+
+    def set_option(self, option, value):
+        """Pins a kernel-variant choice of this handle (OPT_*; -1 hands it back to the library)."""
+        _check(lib().pqd_set_option(self._h, option, value))
+
+    def submit_chunks(self, chunks, pages_list, physical_type, type_length=0, max_def=0, max_rep=0, levels_only=False):
+        """Several chunks of one leaf column in one call: chunks = list of host byte buffers, pages_list = their page
+        descriptor arrays."""
+        arrs = [np.frombuffer(c, dtype=np.uint8) if not isinstance(c, np.ndarray) else np.ascontiguousarray(c, np.uint8) for c in chunks]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+        pg = np.concatenate([np.ascontiguousarray(p, dtype=PAGE_DESC_DTYPE) for p in pages_list]) if n else np.zeros(0, PAGE_DESC_DTYPE)
+        per = (C.c_int32 * max(n, 1))(*[len(p) for p in pages_list])
+        self._pages, self._keep = pg, arrs
+        self._is_bytes = physical_type == BYTE_ARRAY
+        cd = self._col(physical_type, type_length, max_def, max_rep)
+        _check(lib().pqd_decode_chunks(self._h, n, ptrs, lens, C.c_void_p(pg.ctypes.data if pg.size else None), per, C.byref(cd),
+                                       LEVELS_ONLY if levels_only else 0))
+
+    def submit_chunks_device(self, dev_ptrs, nbytes, pages_list, physical_type, type_length=0, max_def=0, max_rep=0, levels_only=False):
+        """The same with the chunk bytes already in device memory (16-byte aligned pointers)."""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * max(n, 1))(*dev_ptrs)
+        lens = (C.c_size_t * max(n, 1))(*nbytes)
+        pg = np.concatenate([np.ascontiguousarray(p, dtype=PAGE_DESC_DTYPE) for p in pages_list]) if n else np.zeros(0, PAGE_DESC_DTYPE)
+        per = (C.c_int32 * max(n, 1))(*[len(p) for p in pages_list])
+        self._pages = pg
+        self._is_bytes = physical_type == BYTE_ARRAY
+        cd = self._col(physical_type, type_length, max_def, max_rep)
+        _check(lib().pqd_decode_chunks_device(self._h, n, ptrs, lens, C.c_void_p(pg.ctypes.data if pg.size else None), per, C.byref(cd),
+                                              LEVELS_ONLY if levels_only else 0))
 
     def submit(self, chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0):
         """Chunk bytes in host memory (bytes / numpy uint8)."""

@@ -20,24 +20,25 @@ __device__ __forceinline__ uint64_t make_pair(int64_t src, int64_t len) { return
 
 // ---------------------------------------------------------------------------------------------
 // PLAIN BYTE_ARRAY: [u32 length][bytes] ... — a serial chain per page; one thread walks one page.
-// which = -1: every PLAIN data page (pairs -> pairs_out[dense_base + i]); else the dictionary page `which`
-// (pairs -> pairs_out[i]).
+// dict_pages == nullptr: every PLAIN data page (pairs -> pairs_out[dense_base + i]); else the listed dictionary
+// pages (pairs -> pairs_out[dict_off + i]).
 // Reference semantics (encodingread.go:98-112): the 4-byte length is read leniently (zero filled when cut),
 // io.EOF only when a value starts exactly at the end.  A string that runs past the page would be zero
 // padded by the reference; here the page is refused (PQD_ERR_REFUSED).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_plain_ba_walk(ChunkCtx c, int which, uint64_t *pairs_out) {
+__global__ void k_plain_ba_walk(ChunkCtx c, const int32_t *__restrict__ dict_pages, int n_dict, uint64_t *pairs_out) {
   int p;
   int64_t cnt, pos, end;
   uint64_t *out;
-  if (which >= 0) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    p = which;
+  if (dict_pages) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_dict) return;
+    p = dict_pages[k];
     const PageIn pi = c.pages[p];
     cnt = pi.num_values;
     pos = pi.body_off;
     end = pi.body_off + pi.body_len;
-    out = pairs_out;
+    out = pairs_out + pi.dict_off;
   } else {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= c.nd) return;
@@ -230,8 +231,12 @@ __global__ __launch_bounds__(256) void k_len_offsets(const uint64_t *__restrict_
 // one contiguous block each: flat 128-bit copy.
 // ---------------------------------------------------------------------------------------------
 // grid.x = data pages, grid.y = slices of the page; pages copied by the two special kernels are skipped
+// (every copy kernel first compares the byte total, doff[n], with the capacity of the output it was given: the
+//  output is sized from an estimate when the call is enqueued, and a call whose strings need more is copied again
+//  into a larger buffer once the total is known)
 __global__ __launch_bounds__(256) void k_copy_values(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, int flat_dlba,
-                                                     uint8_t *bytes_out) {
+                                                     uint8_t *bytes_out, const int64_t *__restrict__ total, int64_t cap) {
+  if (*total > cap) return;
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
   const int enc = c.pages[p].encoding;
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(256) void k_copy_values(ChunkCtx c, const uint64_t 
 
 struct V16U { uint32_t v[4]; } __attribute__((packed));
 
-__global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out) {
+__global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
+                                                         const int64_t *__restrict__ total, int64_t cap) {
   // grid.x = data pages, grid.y = slices of the page
+  if (*total > cap) return;
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
@@ -344,10 +351,12 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane
 
 __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
                                                                 const uint64_t *__restrict__ pairs, const int64_t *__restrict__ doff,
-                                                                const int32_t *__restrict__ page_flag, uint8_t *__restrict__ bytes_out) {
+                                                                const int32_t *__restrict__ page_flag, uint8_t *__restrict__ bytes_out,
+                                                                const int64_t *__restrict__ total, int64_t cap) {
   __shared__ uint8_t s_cur_all[kChainWaves][kChainMax + 64];
   __shared__ __align__(16) uint8_t s_stage_all[kChainWaves][kStageBytes];
   __shared__ int s_bnd[kChainWaves + 1];
+  if (*total > cap) return;
   const int d = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint8_t *s_cur = s_cur_all[wave];
@@ -540,7 +549,9 @@ __global__ __launch_bounds__(1024) void k_dba_parents(ChunkCtx c, int64_t *prefi
 
 // one thread per string: suffix bytes straight, prefix bytes through the parent chain
 __global__ __launch_bounds__(256) void k_dba_resolve(ChunkCtx c, const int64_t *prefix, const uint64_t *pairs, const int32_t *parent,
-                                                     const int64_t *doff, const int32_t *page_flag, uint8_t *bytes_out) {
+                                                     const int64_t *doff, const int32_t *page_flag, uint8_t *bytes_out,
+                                                     const int64_t *__restrict__ total, int64_t cap) {
+  if (*total > cap) return;
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] == 0) return;
@@ -609,9 +620,9 @@ __global__ __launch_bounds__(256) void k_scatter_offsets(const int32_t *def, int
 }
 
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_out, hipStream_t stream) {
-  if (which >= 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3(1), dim3(64), 0, stream, c, which, pairs_out);
-  else if (c.nd > 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3((c.nd + 63) / 64), dim3(64), 0, stream, c, which, pairs_out);
+hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint64_t *pairs_out, hipStream_t stream) {
+  if (dict_pages) { if (n_dict > 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3((n_dict + 63) / 64), dim3(64), 0, stream, c, dict_pages, n_dict, pairs_out); }
+  else if (c.nd > 0) hipLaunchKernelGGL(k_plain_ba_walk, dim3((c.nd + 63) / 64), dim3(64), 0, stream, c, dict_pages, 0, pairs_out);
   return hipGetLastError();
 }
 
@@ -651,29 +662,31 @@ hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int6
 }
 
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
-                              hipStream_t stream) {
+                              const int64_t *total, int64_t cap, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_copy_values, dim3(c.nd, 16), dim3(256), 0, stream, c, pairs, doff, flat_dlba, bytes_out);
+  hipLaunchKernelGGL(k_copy_values, dim3(c.nd, c.nd > 4096 ? 1 : 16), dim3(256), 0, stream, c, pairs, doff, flat_dlba, bytes_out, total, cap);
   return hipGetLastError();
 }
 
-hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out, hipStream_t stream) {
+hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
+                                  const int64_t *total, int64_t cap, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_copy_dlba_pages, dim3(c.nd, 32), dim3(256), 0, stream, c, pairs, doff, bytes_out);
+  hipLaunchKernelGGL(k_copy_dlba_pages, dim3(c.nd, c.nd > 4096 ? 2 : 32), dim3(256), 0, stream, c, pairs, doff, bytes_out, total, cap);
   return hipGetLastError();
 }
 
 // phase 0: before the offsets exist (prefix checks, page classes, parent links of the pages with long strings);
 // phase 1: the copies
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
-                              int32_t *page_flag, uint8_t *bytes_out, int phase, hipStream_t stream) {
+                              int32_t *page_flag, uint8_t *bytes_out, int phase, const int64_t *total, int64_t cap,
+                              hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (phase == 0) {
     hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag);
     hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent, page_flag);
   } else {
-    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out);
-    hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out);
+    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out, total, cap);
+    hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out, total, cap);
   }
   return hipGetLastError();
 }

@@ -5,7 +5,6 @@
 // Reference behaviour reproduced here: encoding/encodingread.go:146-167 (RLE run), :170-228 (bit-packed run),
 // layout/page.go:139-164 (dictionary gather), :835-888 (levels, null count), :925-927 (row count).
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "pqd_kernels.h"
 
 namespace pqd {
@@ -23,10 +22,12 @@ struct ExpandArgs {
   const int32_t *tile_prefix;  // n_streams + 1 entries
   const int32_t *tile_stream;  // n_tiles entries: stream (relative to stream0) of each tile
   int stream0;
+  int tile_lo;                 // this launch expands the tiles [tile_lo, n_tiles)
   int n_tiles;
   int32_t *rep_out, *def_out;  // levels
   const uint8_t *dict;         // dictionary, elem_size bytes per entry, 16-byte aligned and padded
   int32_t dict_n;
+  int32_t no_dict;             // the pages of this launch have no dictionary: their indices pass through unchecked
   int32_t dict_lds_n;          // entries [0, dict_lds_n) are staged in LDS
   int32_t dict_lds_bytes;      // LDS reserved for them (multiple of 16)
   int32_t runs_cap;            // run-slice entries a group keeps in LDS (+ 3)
@@ -87,7 +88,7 @@ __device__ __forceinline__ void decode4(const RunEntry *R, int nr, int v, int n4
 // k_tile_desc: one thread per tile, after the prescan: which runs, items and stream bytes the tile covers.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
-  const int tile = blockIdx.x * 256 + threadIdx.x;
+  const int tile = a.tile_lo + blockIdx.x * 256 + threadIdx.x;
   if (tile >= a.n_tiles) return;
   const ChunkCtx &c = a.c;
   TileDesc d;
@@ -135,7 +136,11 @@ __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
   d.org = b_lo - (int)((reinterpret_cast<uintptr_t>(c.in + d.in_off) + (uintptr_t)(uint32_t)b_lo) & 15u);
   d.span = b_hi - d.org;
   const bool in_lds = d.nr <= a.runs_cap + 2 && d.span + 8 <= a.stage_bytes && d.n_items <= a.mark_cap;
-  d.flags = 1 | (in_lds ? 2 : 0) | ((a.stream0 + ls) >= c.nd ? 4 : 0);
+  // bit 3: the values are the unpacked numbers themselves (Encoding_RLE data pages, layout/page.go:657-667)
+  // (also set for dictionary-encoded pages that have no dictionary page in front of them: the call fails for them
+  //  with its own code, and the stream's own errors, which come first in the reference, are still found)
+  const bool ident = a.stream0 >= 2 * c.nd && (c.pages[sp->page].encoding == PQD_ENC_RLE || a.no_dict);
+  d.flags = 1 | (in_lds ? 2 : 0) | ((a.stream0 + ls) >= c.nd ? 4 : 0) | (ident ? 8 : 0);
   a.descs[tile] = d;
 }
 
@@ -227,6 +232,7 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
   const int lane = gtid & 63;
   const int tn = d.t1 - d.t0;
   const bool is_def = (d.flags & 4) != 0;
+  const bool ident = MODE != 0 && (d.flags & 8) != 0;
   const bool check_bp = MODE != 0 && !(W < 32 && (1u << (W & 31)) <= (uint32_t)a.dict_n);  // can a packed index be out of range
   for (int q0 = gtid - lane; q0 < d.n_items; q0 += GT) {
     const int q = q0 + lane;
@@ -270,6 +276,17 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       for (int j = 0; j < 8; j++) n_flag += (j >= j0 && j < j1) && (is_def ? (x[j] != cmp) : (x[j] == cmp));
       store_item(reinterpret_cast<uint32_t *>(outp), x, j0, j1);
     } else if (MODE == 4 || MODE == 8) {
+      if (ident) {
+        // int32(value) / int64(value): the unpacked numbers are zero extended (encodingread.go:160, :202)
+        if (MODE == 4) store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, x, j0, j1);
+        else {
+          uint64_t y[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) y[j] = x[j];
+          store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
+        }
+        continue;
+      }
       if (bp ? check_bp : true) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -288,6 +305,13 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       }
     } else {
       const int esz = c.elem_size;
+      if (ident) {
+        for (int j = j0; j < j1; j++) {
+          uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
+          for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(x[j] >> (8 * bb)) : (uint8_t)0;
+        }
+        continue;
+      }
       for (int j = j0; j < j1; j++) {
         uint32_t idx = x[j];
         if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
@@ -333,10 +357,10 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
   for (int i = gtid; i < marks_lds_bytes(a.mark_cap) / 16; i += GT) reinterpret_cast<uint4 *>(s_mark)[i] = make_uint4(0, 0, 0, 0);
 
   const int stride = (int)gridDim.x * G;
-  int tile = (int)blockIdx.x * G + g;
+  int tile = a.tile_lo + (int)blockIdx.x * G + g;
   TileDesc d_next = {};
   if (tile < a.n_tiles) d_next = descs[tile];
-  for (int base = (int)blockIdx.x * G; base < a.n_tiles; base += stride, tile += stride) {
+  for (int base = a.tile_lo + (int)blockIdx.x * G; base < a.n_tiles; base += stride, tile += stride) {
     const TileDesc d = d_next;
     d_next.flags = 0;
     if (tile + stride < a.n_tiles) d_next = descs[tile + stride];  // in flight while this tile is expanded
@@ -419,8 +443,12 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
         } else {
           for (int j = 0; j < n4; j++) {
             uint32_t idx = x[j];
-            if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
             uint8_t *dst = a.values_out + (size_t)(d.out_elem + v + j) * esz;
+            if (d.flags & 8) {
+              for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(idx >> (8 * bb)) : (uint8_t)0;
+              continue;
+            }
+            if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
             const uint8_t *src = a.dict + (size_t)idx * esz;
             if (MODE == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
             else if (MODE == 8) *reinterpret_cast<uint64_t *>(dst) = *reinterpret_cast<const uint64_t *>(src);
@@ -463,7 +491,7 @@ static hipError_t launch_expand(K kern, const ExpandArgs &a, int grid, int threa
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_tile_desc, dim3((a.n_tiles + 255) / 256), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_tile_desc, dim3((a.n_tiles - a.tile_lo + 255) / 256), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), shmem, stream, a, a.descs);
   return hipGetLastError();
 }
@@ -473,8 +501,8 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
                                 hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 0; a.n_tiles = n_tiles;
-  a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.dict_lds_n = 0; a.dict_lds_bytes = 0;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 0; a.tile_lo = 0; a.n_tiles = n_tiles;
+  a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.no_dict = 0; a.dict_lds_n = 0; a.dict_lds_bytes = 0;
   a.values_out = nullptr; a.descs = descs;
   set_group_layout(a, kRunSlice, stage_bytes);
   int per_cu = kLdsTotal / (a.group_bytes + 512);
@@ -484,12 +512,15 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
   return launch_expand(&k_hybrid_expand<0, 0, 1, 256>, a, grid, 256, (size_t)a.group_bytes, stream);
 }
 
-hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int tile_lo, int tile_hi,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, bool shared_gpu, hipStream_t stream) {
-  if (n_tiles <= 0) return hipSuccess;
+                              int n_cu, bool shared_gpu, int split_mode, hipStream_t stream) {
+  if (tile_hi <= tile_lo) return hipSuccess;
+  const int n_tiles = tile_hi - tile_lo;   // tiles of this launch (grid sizing)
   ExpandArgs a;
-  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 2 * c.nd; a.n_tiles = n_tiles;
+  a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 2 * c.nd; a.tile_lo = tile_lo; a.n_tiles = tile_hi;
+  a.no_dict = dict_n < 0;
+  if (dict_n < 0) dict_n = 0;
   a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out; a.descs = descs;
   const int esz = c.elem_size;
   const size_t dict_bytes = ((size_t)dict_n * esz + 15) / 16 * 16;
@@ -498,8 +529,8 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   // shared_gpu: other chunks are being decoded at the same time.  The variant below that keeps the head of a
   // mid-size dictionary in LDS takes a whole CU per workgroup and so shuts the other chunks' kernels out; with
   // company the plain gather is the better neighbour.
-  static const char *force = std::getenv("PQD_SPLIT");  // "0" / "1": pin the choice (tests)
-  const bool no_split = force ? force[0] == '0' : shared_gpu;
+  // split_mode 0 / 1 pins the choice (tests), -1 leaves it to the situation
+  const bool no_split = split_mode >= 0 ? split_mode == 0 : shared_gpu;
   if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024 || no_split) {
     // small dictionaries: whole dictionary in the LDS of every block, several 256-thread blocks per CU.
     // Large ones of other element sizes, and very large ones: gathered from L2 / HBM.

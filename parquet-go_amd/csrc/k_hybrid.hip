@@ -735,6 +735,21 @@ __global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c) {
       vs->status = st;
     }
   }
+  // Encoding_RLE values (layout/page.go:657-667): ReadRLEBitPackedHybrid with the column's type length as the bit
+  // width and a 4-byte length prefix in front of the runs; the numbers are the values (int32(value) for INT32).
+  // Typed output exists for BOOLEAN (low byte), INT32 and INT64; the other types are refused on the host.
+  if (ps->status == 0 && cnt > 0 && pi.encoding == PQD_ENC_RLE &&
+      (c.physical_type == PQD_BOOLEAN || c.physical_type == PQD_INT32 || c.physical_type == PQD_INT64)) {
+    int64_t pos = ps->val_off;
+    int st = c.type_length < 0 ? PQD_ERR_MALFORMED : take_prefixed_v1(c.in, pos, ps->val_off + ps->val_len, *vs);
+    if (st == 0) {
+      vs->w = c.type_length;
+      vs->cnt = (int32_t)cnt;
+    } else {
+      ps->status = st;
+      vs->status = st;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -753,7 +768,7 @@ constexpr int kDirectMaxLen = 64 * 1024;
 // layout/page.go:234-238); the values are the levels themselves, and the nulls (definition level below the maximum)
 // or row starts (repetition level 0) are counted into the page state as the tile expansion would.
 template <typename T, bool kLevels>
-__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict, int dict_n, T *__restrict__ values_out,
+__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
                                                         int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
   __shared__ uint32_t s_sum[4];
   __shared__ int s_flag[4];
@@ -763,6 +778,15 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   Stream *sp = &c.streams[si];
   const int w = sp->w, cnt = sp->cnt, len = sp->len;
   if (sp->status != 0 || cnt <= 0 || w <= 0 || w > 32 || len != sp->avail || len <= 0 || len > kDirectMaxLen) return;
+  const T *dict = nullptr;
+  int dict_n = 0;
+  if (!kLevels) {
+    // dictionary-encoded pages only, looked up in the dictionary in effect for the page
+    const PageIn &pg = c.pages[sp->page];
+    if ((pg.encoding != PQD_ENC_PLAIN_DICTIONARY && pg.encoding != PQD_ENC_RLE_DICTIONARY) || pg.dict_page < 0) return;
+    dict = dict_table + pg.dict_off;
+    dict_n = pg.dict_n;
+  }
   const uint32_t nb = (uint32_t)(w + 7) / 8, stride = 1u + nb;
   if ((uint32_t)len % stride) return;
   const int n_runs = (int)((uint32_t)len / stride);
@@ -829,20 +853,20 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   if (tid == 0) { sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)total; }
 }
 
-hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream) {
+hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict_table, uint8_t *values_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (c.elem_size == 4)
-    hipLaunchKernelGGL((k_rle_only_pages<uint32_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint32_t *>(dict), dict_n,
+    hipLaunchKernelGGL((k_rle_only_pages<uint32_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint32_t *>(dict_table),
                        reinterpret_cast<uint32_t *>(values_out), (int32_t *)nullptr, (int32_t *)nullptr);
   else if (c.elem_size == 8)
-    hipLaunchKernelGGL((k_rle_only_pages<uint64_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint64_t *>(dict), dict_n,
+    hipLaunchKernelGGL((k_rle_only_pages<uint64_t, false>), dim3(c.nd), dim3(256), 0, stream, c, reinterpret_cast<const uint64_t *>(dict_table),
                        reinterpret_cast<uint64_t *>(values_out), (int32_t *)nullptr, (int32_t *)nullptr);
   return hipGetLastError();
 }
 
 hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *def_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_rle_only_pages<int32_t, true>), dim3(2 * c.nd), dim3(256), 0, stream, c, (const int32_t *)nullptr, 0, (int32_t *)nullptr,
+  hipLaunchKernelGGL((k_rle_only_pages<int32_t, true>), dim3(2 * c.nd), dim3(256), 0, stream, c, (const int32_t *)nullptr, (int32_t *)nullptr,
                      rep_out, def_out);
   return hipGetLastError();
 }

@@ -48,17 +48,32 @@ __device__ __forceinline__ void block_copy_tile(const uint8_t *src, int64_t src_
   }
 }
 
-// ---- dictionary page, fixed-width types: PLAIN values copied to an aligned table ----
-__global__ __launch_bounds__(256) void k_dict_plain_fixed(ChunkCtx c, int dict_page, uint8_t *dict_out) {
+// ---- dictionary pages, fixed-width types: PLAIN values copied to an aligned table ----
+// grid.y = dictionary page of the call (dict_pages lists their page indices); the entries of page dp land at
+// dict_out + pages[dp].dict_off * elem_size.  BOOLEAN dictionaries are one bit per entry, read the way
+// ReadPlainBOOLEAN does (encodingread.go:35-55: io.EOF on an empty section, zero fill on a short one).
+__global__ __launch_bounds__(256) void k_dict_plain_fixed(ChunkCtx c, const int32_t *__restrict__ dict_pages, uint8_t *dict_out) {
+  const int dict_page = dict_pages[blockIdx.y];
   const PageIn pi = c.pages[dict_page];
   const int64_t n = pi.num_values;
+  uint8_t *out = dict_out + pi.dict_off * (int64_t)c.elem_size;
+  if (c.physical_type == PQD_BOOLEAN) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int st = n < 0 ? PQD_ERR_MALFORMED : (n > 0 && pi.body_len <= 0 ? PQD_ERR_EOF : PQD_OK);
+      if (st) set_status1(&c.state[dict_page].status, st);
+    }
+    const uint8_t *src = c.in + pi.body_off;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+      out[i] = (i >> 3) < pi.body_len ? (uint8_t)((src[i >> 3] >> (i & 7)) & 1u) : (uint8_t)0;
+    return;
+  }
   const int64_t bytes = n * (int64_t)c.elem_size;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int st = n < 0 ? PQD_ERR_MALFORMED : plain_fixed_status(c.physical_type, pi.body_len, n, c.elem_size);
     if (st) set_status1(&c.state[dict_page].status, st);
   }
   for (int64_t first = (int64_t)blockIdx.x * kPlainTile; first < bytes; first += (int64_t)gridDim.x * kPlainTile)
-    block_copy_tile(c.in + pi.body_off, pi.body_len, dict_out, bytes, first, kPlainTile, c.physical_type == PQD_INT96 ? 12 : 0);
+    block_copy_tile(c.in + pi.body_off, pi.body_len, out, bytes, first, kPlainTile, c.physical_type == PQD_INT96 ? 12 : 0);
 }
 
 // ---- data pages, PLAIN fixed-width values ----
@@ -470,8 +485,9 @@ hipError_t launch_row_starts(const int32_t *rep_levels, int64_t n_slots, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_dict_plain_fixed, dim3(16), dim3(256), 0, stream, c, dict_page, dict_out);
+hipError_t launch_dict_plain_fixed(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint8_t *dict_out, hipStream_t stream) {
+  if (n_dict <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dict_plain_fixed, dim3(n_dict > 64 ? 2 : 16, n_dict), dim3(256), 0, stream, c, dict_pages, dict_out);
   return hipGetLastError();
 }
 

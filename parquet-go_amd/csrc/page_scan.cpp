@@ -75,7 +75,7 @@ extern "C" int pqd_scan_pages(const uint8_t *chunk, size_t len, int64_t total_va
       return PQD_ERR_THRIFT;
     }
     if ((uint64_t)d.length > c.n - c.i) { *n_out = n; return PQD_ERR_UNEXPECTED_EOF; }  // io.ReadFull of the body
-    if (n >= cap) { *n_out = n; return PQD_ERR_NOMEM; }
+    if (n >= cap) { *n_out = n; return PQD_ERR_CAPACITY; }
     out[n++] = d;
     if (d.page_type == PQD_DATA_PAGE || d.page_type == PQD_DATA_PAGE_V2) covered += d.num_values;
     c.i += (size_t)d.length;

@@ -1,12 +1,13 @@
-// C ABI of libpqdecode.so: handles, workspaces and the per-chunk kernel sequence.
+// C ABI of libpqdecode.so: handles, workspaces and the kernel sequence of one decode call.
 //
-// Mirrors, per column chunk, the loop ColumnBufferType.ReadPage runs per page
-// (reader/columnbuffer.go:105-156): layout.ReadPage (layout/page.go:721-937) -> Page.Decode (:139-164)
-// -> Table.Merge (layout/table.go:52-71).
+// Mirrors, for the pages of one or more column chunks of a leaf column, the loop ColumnBufferType.ReadPage runs per
+// page (reader/columnbuffer.go:105-156): layout.ReadPage (layout/page.go:721-937) -> Page.Decode (:139-164)
+// -> Table.Merge (layout/table.go:52-71), with the row-group advance of NextRowGroup (:53-103) between chunks.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,12 +36,37 @@ int fail_arg(const char *what) {
     if (_e != hipSuccess) return fail_hip(_e, #expr); \
   } while (0)
 
-// grow-only device buffer
+// Nothing may unwind across the C ABI: allocation failures of the host containers become PQD_ERR_NOMEM.
+#define PQD_GUARDED(...)                                                              \
+  try { __VA_ARGS__ }                                                                 \
+  catch (const std::bad_alloc &) { g_last_error = "host allocation failed"; return PQD_ERR_NOMEM; } \
+  catch (...) { g_last_error = "unexpected exception"; return PQD_ERR_INVALID_ARG; }
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// A fixed region of device memory that buffers are carved from, one call at a time (the entry point that may not
+// allocate works out of one).
+struct Arena {
+  uint8_t *base = nullptr;
+  size_t cap = 0, used = 0;
+};
+
+// Device buffer of a handle.  By default it owns its memory and only ever grows; with `arena` set it is carved
+// anew from the arena on every call; with `fixed` set it is memory of the caller and never changes.
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  Arena *arena = nullptr;
+  bool fixed = false;
   int ensure(size_t n) {
     if (n <= cap) return PQD_OK;
+    if (fixed) { g_last_error = "an output buffer of the caller is too small"; return PQD_ERR_INVALID_ARG; }
+    if (arena) {
+      const size_t at = align_up(arena->used, 256), want = align_up(n, 256);
+      if (at + want > arena->cap) { g_last_error = "the call needs more work space than this entry point holds"; return PQD_ERR_NOMEM; }
+      p = arena->base + at; cap = want; arena->used = at + want;
+      return PQD_OK;
+    }
     size_t want = std::max(n, cap + cap / 2);
     want = (want + 255) / 256 * 256;
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return fail_hip(e, "hipFree"); }
@@ -49,28 +75,66 @@ struct DevBuf {
     cap = want;
     return PQD_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !arena && !fixed) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct PinnedBuf {
+// Host staging.  Page-locked by default; `pageable` (the entry point that may not allocate device or page-locked
+// memory) keeps it in ordinary heap memory, which HIP copies through its own staging.
+struct HostBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool pageable = false;
   int ensure(size_t n) {
     if (n <= cap) return PQD_OK;
-    size_t want = std::max(n, cap + cap / 2);
+    const size_t want = std::max(n, cap + cap / 2);
+    if (pageable) {
+      void *q = std::realloc(p, want);
+      if (!q) { g_last_error = "host allocation failed"; return PQD_ERR_NOMEM; }
+      p = q; cap = want;
+      return PQD_OK;
+    }
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipHostMalloc"); }
     cap = want;
     return PQD_OK;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() {
+    if (p) { if (pageable) std::free(p); else (void)hipHostFree(p); }
+    p = nullptr; cap = 0;
+  }
 };
 
 struct KernelEvent {
   const char *name;
   hipEvent_t start, stop;
 };
+
+// Process-wide defaults of the per-handle options, read from the environment once (PQD_PRESCAN=wide|wave,
+// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_HEAVY_LANES=0..4).
+struct Defaults {
+  int opt[PQD_OPT_COUNT];
+  int heavy_lanes;
+};
+constexpr int kMaxLanes = 4;
+const Defaults &defaults() {
+  static const Defaults d = [] {
+    Defaults x;
+    for (int &o : x.opt) o = -1;
+    x.opt[PQD_OPT_POISON] = 0;
+    if (const char *e = std::getenv("PQD_PRESCAN")) x.opt[PQD_OPT_PRESCAN] = (e[0] == 'w' && e[1] == 'i') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 0 : -1;
+    if (const char *e = std::getenv("PQD_DIRECT_RLE")) x.opt[PQD_OPT_DIRECT_RLE] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_JUMP")) x.opt[PQD_OPT_JUMP] = e[0] == '1';
+    if (std::getenv("PQD_NO_PLAIN_SCATTER")) x.opt[PQD_OPT_PLAIN_SCATTER] = 0;
+    if (const char *e = std::getenv("PQD_SPLIT")) x.opt[PQD_OPT_SPLIT] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_POISON")) x.opt[PQD_OPT_POISON] = e[0] == '1';
+    const char *e = std::getenv("PQD_HEAVY_LANES");
+    const int v = e ? std::atoi(e) : 0;
+    x.heavy_lanes = v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
+    return x;
+  }();
+  return d;
+}
 
 }  // namespace
 
@@ -80,15 +144,21 @@ struct pqd_handle {
   bool own_stream = false;
   int n_cu = 256;
   bool profiling = false;
+  bool no_alloc = false;             // work space from an arena, outputs in the caller's memory, nothing page-locked
+  int opt[PQD_OPT_COUNT];
 
   DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
   DevBuf row_starts, dba_flags;
   int64_t bytes_len = 0;
-  PinnedBuf stage_in, stage_out, stage_meta, host_small;
+  HostBuf stage_in[2], stage_out, stage_meta, host_small;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr};   // the copy out of stage_in[k] has been done
+  bool h2d_pending[2] = {false, false};
+  int stage_next = 0;
 
   // description of the last decode call
   std::vector<PageIn> h_pages;
+  std::vector<int32_t> h_dict_pages;
   pqd_column_desc col{};
   int n_pages = 0, nd = 0;
   int64_t total_slots = 0;
@@ -99,10 +169,20 @@ struct pqd_handle {
   pqd_chunk_result result{};
   ChunkCtx ctx{};
 
+  // BYTE_ARRAY: what the byte copies of the last call consist of (they are enqueued against an estimate of the
+  // output size and done again by pqd_wait when the strings turn out to need more)
+  struct BytesPlan {
+    bool active = false, any_plain = false, any_dict_enc = false, any_dlba = false, any_dba = false, nullable = false;
+    int64_t slots = 0;
+  } plan;
+
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;  // hand-over to and from the device's shared stream
 
   std::vector<KernelEvent> events;   // pool
   size_t n_events = 0;               // used by the last call
+
+  DevBuf *all_bufs_[22] = {&in, &meta, &runs, &tile_run, &tile_desc, &dict, &values, &dense, &def, &rep, &offsets, &bytes,
+                           &scratch, &small, &pairs, &lens64, &prefix64, &parent, &doff, &dict_pairs, &row_starts, &dba_flags};
 };
 
 namespace {
@@ -142,10 +222,21 @@ int elem_size_of(const pqd_column_desc &c) {
   }
 }
 
-// Handles with a decode in flight (submitted, not yet waited for), over the whole process.  A chunk decoded while
-// others are in flight gets the kernel variants that leave most of each CU to them; a lone chunk gets the ones
-// that use the whole GPU to cut its latency.
-std::atomic<int> g_inflight{0};
+// Handles with a decode in flight (submitted, not yet waited for), per device.  A chunk decoded while others are in
+// flight on its GPU gets the kernel variants that leave most of each CU to them; a lone chunk gets the ones that
+// use the whole GPU to cut its latency.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_inflight[kMaxDevices];
+
+void set_busy(pqd_handle *h, bool busy) {
+  if (busy == h->busy) return;
+  h->busy = busy;
+  if (h->device >= 0 && h->device < kMaxDevices) g_inflight[h->device].fetch_add(busy ? 1 : -1, std::memory_order_relaxed);
+}
+int inflight_others(const pqd_handle *h) {
+  if (h->device < 0 || h->device >= kMaxDevices) return 0;
+  return g_inflight[h->device].load(std::memory_order_relaxed) - (h->busy ? 1 : 0);
+}
 
 // Optional shared streams per device for the bandwidth-bound expansion kernels (PQD_HEAVY_LANES = 1..4): every
 // handle walks run headers on its own stream and hands the expansion over to a shared one, so that at most that
@@ -154,23 +245,12 @@ std::atomic<int> g_inflight{0};
 // per-kernel durations that say little (each kernel holds a fraction of the CUs for several times its
 // stand-alone duration).
 std::mutex g_heavy_mu;
-constexpr int kMaxLanes = 4;
-hipStream_t g_heavy[64][kMaxLanes] = {};
+hipStream_t g_heavy[kMaxDevices][kMaxLanes] = {};
 std::atomic<unsigned> g_heavy_next{0};
 
-// PQD_HEAVY_LANES: shared streams per device (0: none, every handle expands on its own stream)
-int heavy_lanes() {
-  static const int n = [] {
-    const char *e = std::getenv("PQD_HEAVY_LANES");
-    int v = e ? std::atoi(e) : 0;
-    return v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
-  }();
-  return n;
-}
-
 hipStream_t heavy_stream(int device) {
-  const int lanes = heavy_lanes();
-  if (device < 0 || device >= 64 || lanes == 0) return nullptr;
+  const int lanes = defaults().heavy_lanes;
+  if (device < 0 || device >= kMaxDevices || lanes == 0) return nullptr;
   const int lane = (int)(g_heavy_next.fetch_add(1, std::memory_order_relaxed) % (unsigned)lanes);
   std::lock_guard<std::mutex> lk(g_heavy_mu);
   if (!g_heavy[device][lane]) {
@@ -183,67 +263,115 @@ hipStream_t heavy_stream(int device) {
 
 bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY; }
 
-size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// layout of the 256-byte block every call copies back: totals | status | byte total
+constexpr int kSmallStatus = 16;       // int32 index: [16] status, [17] bad page
+constexpr int kSmallByteTotal = 16;    // int64 index: byte total of a BYTE_ARRAY call
 
-// The whole per-chunk sequence; d_in already holds the chunk bytes.
-int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_page_desc *pages, int32_t n_pages,
-                     const pqd_column_desc *col, bool levels_only = false) {
+// The byte copies of a BYTE_ARRAY call, against the current capacity of h->bytes.
+int launch_byte_copies(pqd_handle *h) {
+  const pqd_handle::BytesPlan &pl = h->plan;
+  const ChunkCtx &c = h->ctx;
+  const uint64_t *pairs = static_cast<const uint64_t *>(h->pairs.p);
+  int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
+  const int64_t *doff = static_cast<const int64_t *>(pl.nullable ? h->doff.p : h->offsets.p);
+  const int64_t *d_total = doff + pl.slots;
+  const int64_t cap = (int64_t)h->bytes.cap - 64;
+  uint8_t *bytes_out = static_cast<uint8_t *>(h->bytes.p);
+  const bool all_dlba = pl.any_dlba && !pl.any_dba && !pl.any_plain && !pl.any_dict_enc;
+  if (pl.any_plain || pl.any_dict_enc || (pl.any_dlba && !all_dlba)) {
+    Prof pf(h, "k_copy_values");
+    HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, d_total, cap, h->stream));
+  }
+  if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, bytes_out, d_total, cap, h->stream)); }
+  if (pl.any_dba) {
+    Prof pf(h, "k_dba_resolve");
+    HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), bytes_out, 1,
+                               d_total, cap, h->stream));
+  }
+  return PQD_OK;
+}
+
+// One decode call over pages of one leaf column.  `base` + PageIn.body_off addresses the page bodies in device
+// memory; chunk_first[k] .. chunk_first[k + 1] are the pages of chunk k and chunk_off[k] is the offset of its byte 0
+// from `base` (the pqd_page_desc offsets are relative to their chunk).
+int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_page_desc *pages, int32_t n_pages,
+                     int32_t n_chunks, const int32_t *chunk_first, const int64_t *chunk_off, const size_t *chunk_len,
+                     const pqd_column_desc *col, bool levels_only) {
+  // a handle runs one call at a time: the page table, the meta block and the work buffers of a call still in
+  // flight are about to be rewritten
+  if (h->busy) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    set_busy(h, false);
+  }
   h->have_result = false;
-  h->levels_only = levels_only;
-  h->n_events = 0;
-  h->col = *col;
-  h->n_pages = n_pages;
+  h->plan = pqd_handle::BytesPlan{};
   const int esz = elem_size_of(*col);
-  h->elem_size = esz;
   if (col->physical_type < 0 || col->physical_type > PQD_FIXED_LEN_BYTE_ARRAY) return fail_arg("unknown physical type");
   if (col->physical_type == PQD_FIXED_LEN_BYTE_ARRAY && col->type_length < 0) return fail_arg("negative type_length");
   if (col->max_def < 0 || col->max_rep < 0) return fail_arg("negative max level");
-  if (reinterpret_cast<uintptr_t>(d_in) & 15u) return fail_arg("device chunk buffer must be 16-byte aligned");
+  if (reinterpret_cast<uintptr_t>(base) & 15u) return fail_arg("device chunk buffer must be 16-byte aligned");
+  const bool is_bytes = col->physical_type == PQD_BYTE_ARRAY;
+  if (is_bytes && span > ((size_t)1 << 40)) return fail_arg("BYTE_ARRAY chunks of one call must lie within 1 TiB of device address space");
+  if (is_bytes && h->no_alloc) return fail_arg("BYTE_ARRAY columns need the allocating entry points");
 
-  // ---- host-side page table ----
+  // ---- host-side page table; the dictionary in effect follows the page order of each chunk ----
   h->h_pages.resize((size_t)n_pages);
-  int nd = 0, dict_page = -1, n_dict = 0;
-  int64_t slots = 0;
+  h->h_dict_pages.clear();
+  int nd = 0;
+  int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0;
   int host_status = PQD_OK, host_bad = -1;
-  bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_other = false;
+  bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_rle = false;
+  bool any_dlba = false, any_dba = false;
   const bool is_real = col->physical_type == PQD_FLOAT || col->physical_type == PQD_DOUBLE;
-  for (int p = 0; p < n_pages; p++) {
-    const pqd_page_desc &d = pages[p];
-    PageIn &pi = h->h_pages[(size_t)p];
-    if (d.offset < 0 || d.length < 0 || (uint64_t)d.offset + (uint64_t)d.length > len) return fail_arg("page outside the chunk buffer");
-    if (d.length > 0x7FFFFFF0ll) return fail_arg("page larger than 2 GiB");
-    pi.body_off = d.offset; pi.body_len = d.length; pi.page_type = d.page_type; pi.encoding = d.encoding;
-    pi.num_values = d.num_values; pi.rep_len = d.rep_len; pi.def_len = d.def_len; pi.slot_base = slots;
-    pi.data_idx = -1;
-    if (d.page_type == PQD_DATA_PAGE || d.page_type == PQD_DATA_PAGE_V2) {
-      pi.data_idx = nd++;
-      if (d.num_values > 0) slots += d.num_values;
-      if (is_dict_enc(d.encoding)) any_dict_enc = true;
-      else if (d.encoding == PQD_ENC_PLAIN) any_plain = true;
-      else if (d.encoding == PQD_ENC_DELTA_BINARY_PACKED) any_delta = true;
-      else if (d.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real) any_bss = true;  // layout/page.go:707-714
-      else any_other = true;
-    } else if (d.page_type == PQD_DICTIONARY_PAGE) {
-      if (n_dict == 0) dict_page = p;
-      n_dict++;
-    } else if (host_status == PQD_OK) {
-      host_status = PQD_ERR_UNSUPPORTED_PAGE_TYPE; host_bad = p;   // INDEX_PAGE and unknown types, layout/page.go:813,934
+  const bool rle_typed = col->physical_type == PQD_BOOLEAN || col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64;
+  auto host_fail = [&](int code, int page) { if (host_status == PQD_OK) { host_status = code; host_bad = page; } };
+  for (int ch = 0; ch < n_chunks; ch++) {
+    int cur_dict = -1;   // DictPage = nil at every row group (reader/columnbuffer.go:101)
+    if (chunk_first[ch] < 0 || chunk_first[ch + 1] < chunk_first[ch] || chunk_first[ch + 1] > n_pages) return fail_arg("bad page counts");
+    for (int p = chunk_first[ch]; p < chunk_first[ch + 1]; p++) {
+      const pqd_page_desc &d = pages[p];
+      PageIn &pi = h->h_pages[(size_t)p];
+      if (d.offset < 0 || d.length < 0 || (uint64_t)d.offset + (uint64_t)d.length > chunk_len[ch]) return fail_arg("page outside the chunk buffer");
+      if (d.length > 0x7FFFFFF0ll) return fail_arg("page larger than 2 GiB");
+      pi.body_off = chunk_off[ch] + d.offset; pi.body_len = d.length; pi.page_type = d.page_type; pi.encoding = d.encoding;
+      pi.num_values = d.num_values; pi.rep_len = d.rep_len; pi.def_len = d.def_len; pi.slot_base = slots;
+      pi.data_idx = -1; pi.dict_page = -1; pi.dict_n = 0; pi.dict_off = 0;
+      all_bytes += d.length;
+      if (d.page_type == PQD_DATA_PAGE || d.page_type == PQD_DATA_PAGE_V2) {
+        pi.data_idx = nd++;
+        data_bytes += d.length;
+        if (d.num_values > 0) slots += d.num_values;
+        if (cur_dict >= 0) {
+          const PageIn &dp = h->h_pages[(size_t)cur_dict];
+          pi.dict_page = cur_dict; pi.dict_n = dp.dict_n; pi.dict_off = dp.dict_off;
+        }
+        const int e = d.encoding;
+        if (is_dict_enc(e)) {
+          any_dict_enc = true;
+          // Page.Decode(nil) leaves the indices in place of the values (layout/page.go:139-143): no typed result
+          if (cur_dict < 0 && !levels_only) host_fail(PQD_ERR_NO_DICTIONARY, p);
+        } else if (e == PQD_ENC_PLAIN) any_plain = true;
+        else if (is_bytes && e == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) any_dlba = true;
+        else if (is_bytes && e == PQD_ENC_DELTA_BYTE_ARRAY) any_dba = true;
+        else if (!is_bytes && e == PQD_ENC_DELTA_BINARY_PACKED && (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64)) any_delta = true;
+        else if (!is_bytes && e == PQD_ENC_BYTE_STREAM_SPLIT && is_real) any_bss = true;   // layout/page.go:707-714
+        else if (!is_bytes && e == PQD_ENC_RLE && rle_typed) any_rle = true;               // layout/page.go:657-667
+        else if (!levels_only) host_fail(e == PQD_ENC_RLE ? PQD_ERR_UNSUPPORTED_TYPE : PQD_ERR_UNSUPPORTED_ENCODING, p);  // layout/page.go:671, :682, :713, :716
+      } else if (d.page_type == PQD_DICTIONARY_PAGE) {
+        pi.dict_page = p; pi.dict_n = d.num_values > 0 ? d.num_values : 0; pi.dict_off = dict_total;
+        dict_total += pi.dict_n;
+        cur_dict = p;
+        h->h_dict_pages.push_back(p);
+      } else {
+        host_fail(PQD_ERR_UNSUPPORTED_PAGE_TYPE, p);   // INDEX_PAGE and unknown types, layout/page.go:813,934
+      }
     }
   }
-  if (n_dict > 1) return fail_arg("more than one dictionary page in a chunk is not supported");
-  h->nd = nd;
-  h->total_slots = slots;
-  const bool is_bytes = col->physical_type == PQD_BYTE_ARRAY;
-  h->bytes_len = 0;
-  bool any_dlba = false, any_dba = false;
-  for (int p = 0; p < n_pages; p++) {
-    const PageIn &pi = h->h_pages[(size_t)p];
-    if (pi.data_idx < 0) continue;
-    if (pi.encoding == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) any_dlba = true;
-    if (pi.encoding == PQD_ENC_DELTA_BYTE_ARRAY) any_dba = true;
-  }
+  if (slots > 0x7FFFFFFF0ll) return fail_arg("too many level slots in one call");
+  const int n_dict = (int)h->h_dict_pages.size();
 
-  // ---- meta block: pages | state | streams | tile prefixes | totals | status ----
+  // ---- meta block: pages | seeds | tile prefixes | tile -> stream maps | dictionary pages; then, device only,
+  //      state | streams ----
   const size_t n_streams = (size_t)3 * nd;
   std::vector<StreamSeed> h_seeds(n_streams);
   std::vector<int32_t> tp_levels(2 * (size_t)nd + 1, 0), tp_dict((size_t)nd + 1, 0), tp_plain((size_t)nd + 1, 0);
@@ -258,7 +386,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
         const int d = pi.data_idx;
         StreamSeed &s = h_seeds[(size_t)g * nd + d];
         const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
-        const bool want = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) || (g == 2 && is_dict_enc(pi.encoding));
+        const bool want = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) ||
+                          (g == 2 && !levels_only && (is_dict_enc(pi.encoding) || (pi.encoding == PQD_ENC_RLE && rle_typed && !is_bytes)));
         const int64_t tiles = want ? (nv + kTile - 1) / kTile : 0;
         const int64_t rcap = want ? std::min<int64_t>(nv, pi.body_len) + 2 : 0;
         s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total;
@@ -281,7 +410,6 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     tp_dict[(size_t)nd] = (int32_t)t_dc;
     tp_plain[(size_t)nd] = (int32_t)t_pl;
   }
-  // uploaded: pages | seeds | tile prefixes | tile -> stream maps; device only (k_page_setup fills them): state | streams
   const size_t off_pages = 0;
   const size_t off_seeds = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
   const size_t off_tp_lv = align_up(off_seeds + sizeof(StreamSeed) * n_streams, 256);
@@ -289,30 +417,21 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   const size_t off_tp_pl = align_up(off_tp_dc + 4 * tp_dict.size(), 256);
   const size_t off_ts_lv = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
   const size_t off_ts_dc = align_up(off_ts_lv + 4 * (size_t)tp_levels.back(), 256);
-  const size_t upload_bytes = align_up(off_ts_dc + 4 * (size_t)tp_dict.back(), 256);
+  const size_t off_dictp = align_up(off_ts_dc + 4 * (size_t)tp_dict.back(), 256);
+  const size_t upload_bytes = align_up(off_dictp + 4 * (size_t)n_dict, 256);
   const size_t off_state = upload_bytes;
   const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
   const size_t meta_bytes = align_up(off_streams + sizeof(Stream) * n_streams, 256);
+
+  // ---- workspaces and outputs (every allocation of the call happens here, before anything is enqueued) ----
+  if (h->no_alloc) {
+    // carved anew from the arena on every call
+    for (DevBuf *b : h->all_bufs_) if (b->arena) { b->p = nullptr; b->cap = 0; }
+    if (h->small.arena) h->small.arena->used = 0;
+  }
   int rc;
   if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(upload_bytes))) return rc;
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
-  {
-    uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
-    std::memcpy(m + off_pages, h->h_pages.data(), sizeof(PageIn) * (size_t)n_pages);
-    if (n_streams) std::memcpy(m + off_seeds, h_seeds.data(), sizeof(StreamSeed) * n_streams);
-    std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
-    std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
-    std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
-    // tile -> stream maps of the two hybrid expansions, written in place
-    int32_t *ts_lv = reinterpret_cast<int32_t *>(m + off_ts_lv), *ts_dc = reinterpret_cast<int32_t *>(m + off_ts_dc);
-    for (size_t i = 0; i + 1 < tp_levels.size(); i++)
-      for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_lv[t] = (int32_t)i;
-    for (size_t i = 0; i + 1 < tp_dict.size(); i++)
-      for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
-  }
-  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
-
-  // ---- workspaces and outputs ----
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
   if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
   if ((rc = h->tile_desc.ensure(sizeof(TileDesc) * ((size_t)std::max(tp_levels.back(), tp_dict.back()) + 1)))) return rc;
@@ -323,27 +442,62 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   } else if (!is_bytes) {
     if ((rc = h->values.ensure(val_bytes))) return rc;
     if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
+    if (nullable && slots > 0 && (rc = h->scratch.ensure(12 * (size_t)((slots + 4095) / 4096) + 64))) return rc;
   } else {
     const size_t n8 = 8 * ((size_t)slots + 2) + 64;
     if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->offsets.ensure(n8))) return rc;
     if ((any_dlba || any_dba) && (rc = h->lens64.ensure(n8))) return rc;
     if (any_dba && (rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
     if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
-    if ((rc = h->scratch.ensure(8 * ((size_t)slots / 2048 + 8) + 64))) return rc;
+    if ((rc = h->scratch.ensure(8 * ((size_t)(slots + 1 + 4095) / 2048 + 8) + 64))) return rc;
+    // the byte output: every PLAIN / DELTA_LENGTH value lies inside its page, so the page bytes bound it; dictionary
+    // and DELTA_BYTE_ARRAY pages may expand beyond that and are then copied again by pqd_wait
+    if ((rc = h->bytes.ensure((size_t)all_bytes + 64))) return rc;
   }
   if (col->max_def > 0 && (rc = h->def.ensure(4 * (size_t)slots + 64))) return rc;
   if (col->max_rep > 0 && (rc = h->rep.ensure(4 * (size_t)slots + 64))) return rc;
-  int dict_n = 0;
-  if (dict_page >= 0) {
-    dict_n = h->h_pages[(size_t)dict_page].num_values;
-    if (dict_n < 0) dict_n = 0;
-    if (!is_bytes && (rc = h->dict.ensure((size_t)dict_n * (size_t)esz + 64))) return rc;
-    if (is_bytes && (rc = h->dict_pairs.ensure(8 * (size_t)dict_n + 64))) return rc;
+  if (!levels_only) {
+    // (at least one entry, so that a page of an empty dictionary never reads outside the table before its
+    //  out-of-range index is reported)
+    if (!is_bytes && (rc = h->dict.ensure((size_t)std::max<int64_t>(dict_total, 1) * (size_t)std::max(esz, 1) + 64))) return rc;
+    if (is_bytes && (rc = h->dict_pairs.ensure(8 * (size_t)std::max<int64_t>(dict_total, 1) + 64))) return rc;
   }
+
+  // PQD_OPT_POISON: every work and output buffer starts the call filled with 0xFF, so that a kernel reading what an
+  // earlier call (or a failed page) left behind shows up as a difference from the reference or as a refused index
+  if (h->opt[PQD_OPT_POISON] > 0) {
+    for (DevBuf *b : h->all_bufs_)
+      if (b != &h->in && b->p && b->cap) HIP_TRY(hipMemsetAsync(b->p, 0xFF, b->cap, h->stream));
+  }
+
+  h->levels_only = levels_only;
+  h->n_events = 0;
+  h->col = *col;
+  h->n_pages = n_pages;
+  h->elem_size = esz;
+  h->nd = nd;
+  h->total_slots = slots;
+  h->bytes_len = 0;
+  {
+    uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
+    if (n_pages) std::memcpy(m + off_pages, h->h_pages.data(), sizeof(PageIn) * (size_t)n_pages);
+    if (n_streams) std::memcpy(m + off_seeds, h_seeds.data(), sizeof(StreamSeed) * n_streams);
+    std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
+    std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
+    std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
+    if (n_dict) std::memcpy(m + off_dictp, h->h_dict_pages.data(), 4 * (size_t)n_dict);
+    // tile -> stream maps of the two hybrid expansions, written in place
+    int32_t *ts_lv = reinterpret_cast<int32_t *>(m + off_ts_lv), *ts_dc = reinterpret_cast<int32_t *>(m + off_ts_dc);
+    for (size_t i = 0; i + 1 < tp_levels.size(); i++)
+      for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_lv[t] = (int32_t)i;
+    for (size_t i = 0; i + 1 < tp_dict.size(); i++)
+      for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
+  }
+  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
 
   uint8_t *mb = static_cast<uint8_t *>(h->meta.p);
   ChunkCtx c;
-  c.in = d_in; c.in_len = (int64_t)len;
+  c.in = base; c.in_len = (int64_t)span;
   c.pages = reinterpret_cast<const PageIn *>(mb + off_pages);
   c.state = reinterpret_cast<PageState *>(mb + off_state);
   c.streams = reinterpret_cast<Stream *>(mb + off_streams);
@@ -352,13 +506,14 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   c.tile_run = static_cast<int32_t *>(h->tile_run.p);
   c.n_pages = n_pages; c.nd = nd; c.max_def = col->max_def; c.max_rep = col->max_rep;
   c.physical_type = col->physical_type; c.type_length = col->type_length; c.elem_size = esz;
-  c.chunk_status = static_cast<int32_t *>(h->small.p) + 16;
+  c.chunk_status = static_cast<int32_t *>(h->small.p) + kSmallStatus;
   h->ctx = c;
   const int32_t *d_tp_lv = reinterpret_cast<const int32_t *>(mb + off_tp_lv);
   const int32_t *d_tp_dc = reinterpret_cast<const int32_t *>(mb + off_tp_dc);
   const int32_t *d_tp_pl = reinterpret_cast<const int32_t *>(mb + off_tp_pl);
   const int32_t *d_ts_lv = reinterpret_cast<const int32_t *>(mb + off_ts_lv);
   const int32_t *d_ts_dc = reinterpret_cast<const int32_t *>(mb + off_ts_dc);
+  const int32_t *d_dictp = reinterpret_cast<const int32_t *>(mb + off_dictp);
   int64_t *d_totals = static_cast<int64_t *>(h->small.p);
 
   uint8_t *dense_out = static_cast<uint8_t *>(nullable ? h->dense.p : h->values.p);
@@ -374,34 +529,28 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     double bpv = 0.0;
     for (int p = 0; p < n_pages; p++) {
       const PageIn &pi = h->h_pages[(size_t)p];
-      if (pi.data_idx >= 0 && is_dict_enc(pi.encoding) && pi.num_values >= kTile)
-        bpv = std::max(bpv, (double)pi.body_len / (double)pi.num_values);
-      else if (pi.data_idx >= 0 && is_dict_enc(pi.encoding)) bpv = std::max(bpv, 4.25);
+      if (pi.data_idx < 0 || !(is_dict_enc(pi.encoding) || pi.encoding == PQD_ENC_RLE)) continue;
+      if (pi.num_values >= kTile) bpv = std::max(bpv, (double)pi.body_len / (double)pi.num_values);
+      else bpv = std::max(bpv, 4.25);
     }
     stage_dict = (int)(bpv * kTile * 1.25) + 512;
   }
 
   // Few long streams: a workgroup per stream takes the decoding off the serial header walk.  Many short ones
   // (small pages): a wavefront per stream keeps more of them in flight.
-  int64_t data_bytes = 0;
-  for (int p = 0; p < n_pages; p++) if (h->h_pages[(size_t)p].data_idx >= 0) data_bytes += h->h_pages[(size_t)p].body_len;
-  const char *force = std::getenv("PQD_PRESCAN");  // "wide" / "wave": pin the choice (tests)
-  const bool shared_gpu = g_inflight.load(std::memory_order_relaxed) - (h->busy ? 1 : 0) >= 2;
+  const bool shared_gpu = inflight_others(h) >= 2;
   bool wide_dict = !shared_gpu && nd > 0 && nd <= 4 * h->n_cu && data_bytes / nd >= 64 * 1024;
   bool wide_levels = wide_dict && slots / nd >= 256 * 1024;
-  if (force && force[0] == 'w' && force[1] == 'i') wide_dict = wide_levels = true;
-  if (force && force[0] == 'w' && force[1] == 'a') wide_dict = wide_levels = false;
+  if (h->opt[PQD_OPT_PRESCAN] >= 0) wide_dict = wide_levels = h->opt[PQD_OPT_PRESCAN] == 1;
   // Level streams of nullable and nested columns are where runs of a few values each are the rule; dictionary
-  // indices of low-cardinality columns have them too (PQD_JUMP=0|1 pins the choice; the variant costs 6 KiB of LDS
-  // per stream, which the benchmark's crowd of seven chunks does not miss: 5.41 against 5.52 ms per step).
-  bool jump_levels = true, jump_dict = true;
-  // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first (PQD_DIRECT_RLE=0|1)
+  // indices of low-cardinality columns have them too (the variant costs 6 KiB of LDS per stream).
+  const bool jump = h->opt[PQD_OPT_JUMP] != 0;
+  // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first
   bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;
-  if (const char *fd = std::getenv("PQD_DIRECT_RLE")) direct_rle = fd[0] == '1';
-  if (const char *fj = std::getenv("PQD_JUMP")) jump_levels = jump_dict = fj[0] == '1';
+  if (h->opt[PQD_OPT_DIRECT_RLE] >= 0) direct_rle = h->opt[PQD_OPT_DIRECT_RLE] == 1;
 
   // hand-over of the dictionary expansion to the device's shared stream and back
-  hipStream_t heavy = heavy_stream(h->device);
+  hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
   if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
   auto to_heavy = [&]() -> hipError_t {
     if (heavy == h->stream) return hipSuccess;
@@ -414,12 +563,41 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
     return e != hipSuccess ? e : hipStreamWaitEvent(h->stream, h->ev_done, 0);
   };
 
+  // Expansion of the index streams: one launch per run of data pages that share a dictionary (the launch keeps its
+  // dictionary in LDS where it fits); Encoding_RLE pages ride along with whatever launch covers their tiles.
+  auto expand_dict_groups = [&](const ChunkCtx &cc, const uint8_t *table, int entry_size, uint8_t *out) -> int {
+    int p = 0;
+    while (p < n_pages) {
+      while (p < n_pages && h->h_pages[(size_t)p].data_idx < 0) p++;
+      if (p >= n_pages) break;
+      const int dict_of = h->h_pages[(size_t)p].dict_page;
+      const int d_lo = h->h_pages[(size_t)p].data_idx;
+      int d_hi = d_lo, q = p;
+      for (; q < n_pages; q++) {
+        const PageIn &pi = h->h_pages[(size_t)q];
+        if (pi.data_idx < 0) continue;
+        if (pi.dict_page != dict_of) break;
+        d_hi = pi.data_idx + 1;
+      }
+      const int t_lo = tp_dict[(size_t)d_lo], t_hi = tp_dict[(size_t)d_hi];
+      if (t_hi > t_lo) {
+        const PageIn &dp = h->h_pages[(size_t)(dict_of >= 0 ? dict_of : p)];
+        const uint8_t *dptr = dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
+        const int dn = dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
+        HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, t_lo, t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
+                                   shared_gpu && heavy == h->stream, h->opt[PQD_OPT_SPLIT], heavy));
+      }
+      p = q;
+    }
+    return PQD_OK;
+  };
+
   // ---- kernels ----
   if (n_pages > 0) {
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
       if (direct_rle) { Prof pf(h, "k_rle_only_pages(levels)"); HIP_TRY(launch_rle_only_levels(c, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
-      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, jump_levels, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, jump, h->stream)); }
       { Prof pf(h, "k_hybrid_expand<levels>");
         HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
@@ -428,30 +606,26 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
   if (levels_only) {
     // skip path (layout/page.go:433-559): levels, null and row counts; the value sections stay as they are
   } else if (is_bytes) {
-    // ---- BYTE_ARRAY: value descriptors (pairs) per encoding, offsets by a chunk-wide scan, then the copies ----
+    // ---- BYTE_ARRAY: value descriptors (pairs) per encoding, offsets by a scan over all slots, then the copies ----
     ChunkCtx c8 = c;
     c8.elem_size = 8;
     uint64_t *pairs = static_cast<uint64_t *>(h->pairs.p);
     int64_t *lens64 = static_cast<int64_t *>(h->lens64.p);
     int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
-    HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages leave zero lengths behind
+    HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
     // (a dictionary walk that fails part way leaves the remaining entries as they are: they must read as empty
     //  strings, not as whatever the buffer held, because the data pages are still expanded through them)
-    if (dict_page >= 0) HIP_TRY(hipMemsetAsync(h->dict_pairs.p, 0, 8 * (size_t)dict_n + 64, h->stream));
-    if (dict_page >= 0) { Prof pf(h, "k_plain_ba_walk(dict)"); HIP_TRY(launch_plain_ba_walk(c, dict_page, static_cast<uint64_t *>(h->dict_pairs.p), h->stream)); }
+    if (n_dict) HIP_TRY(hipMemsetAsync(h->dict_pairs.p, 0, 8 * (size_t)std::max<int64_t>(dict_total, 1) + 64, h->stream));
+    if (n_dict) { Prof pf(h, "k_plain_ba_walk(dict)"); HIP_TRY(launch_plain_ba_walk(c, d_dictp, n_dict, static_cast<uint64_t *>(h->dict_pairs.p), h->stream)); }
     if (any_dict_enc) {
-      if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
-      else {
-        if (direct_rle) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c8, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n, reinterpret_cast<uint8_t *>(pairs), h->stream)); }
-        { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
-        HIP_TRY(to_heavy());
-        { Prof pf(h, "k_hybrid_expand<dict>", heavy);
-          HIP_TRY(launch_expand_dict(c8, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict_pairs.p), dict_n,
-                                     reinterpret_cast<uint8_t *>(pairs), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu && heavy == h->stream, heavy)); }
-        HIP_TRY(from_heavy());
-      }
+      if (direct_rle) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c8, static_cast<const uint8_t *>(h->dict_pairs.p), reinterpret_cast<uint8_t *>(pairs), h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
+      HIP_TRY(to_heavy());
+      { Prof pf(h, "k_hybrid_expand<dict>", heavy);
+        if ((rc = expand_dict_groups(c8, static_cast<const uint8_t *>(h->dict_pairs.p), 8, reinterpret_cast<uint8_t *>(pairs)))) return rc; }
+      HIP_TRY(from_heavy());
     }
-    if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, -1, pairs, h->stream)); }
+    if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
       { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
@@ -461,119 +635,188 @@ int decode_on_device(pqd_handle *h, const uint8_t *d_in, size_t len, const pqd_p
       { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, h->stream)); }
       { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
-      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, h->stream)); }
+      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
     }
-    for (int p = 0; p < n_pages && host_status == PQD_OK; p++) {
-      const PageIn &pi = h->h_pages[(size_t)p];
-      if (pi.data_idx < 0) continue;
-      const int e = pi.encoding;
-      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && e != PQD_ENC_DELTA_BYTE_ARRAY) {
-        host_status = PQD_ERR_UNSUPPORTED_ENCODING; host_bad = p;
-      }
-    }
-    // the number of non-null values sizes the scan; the byte total sizes the output: two small round trips
-    HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 64, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    const int64_t n_dense = static_cast<const int64_t *>(h->host_small.p)[1];
+    // Offsets: a scan over all `slots` descriptors.  The dense values come first; the descriptors behind them are
+    // the zeros written above, so the entries from the number of values on all equal the byte total.
     int64_t *doff = static_cast<int64_t *>(nullable ? h->doff.p : h->offsets.p);
     HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
     { Prof pf(h, "k_len_offsets");
-      HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, n_dense, static_cast<int64_t *>(h->scratch.p), doff, h->stream)); }
-    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->host_small.p) + 128, doff + n_dense, 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    const int64_t total_bytes = *reinterpret_cast<const int64_t *>(static_cast<const uint8_t *>(h->host_small.p) + 128);
-    if (total_bytes < 0 || total_bytes > ((int64_t)1 << 40)) { g_last_error = "implausible byte total"; return PQD_ERR_MALFORMED; }
-    h->bytes_len = total_bytes;
-    if ((rc = h->bytes.ensure((size_t)total_bytes + 64))) return rc;
-    uint8_t *bytes_out = static_cast<uint8_t *>(h->bytes.p);
-    bool all_dlba = any_dlba && !any_dba && !any_plain && !any_dict_enc;
-    if (any_plain || any_dict_enc || (any_dlba && !all_dlba)) { Prof pf(h, "k_copy_values"); HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, h->stream)); }
-    if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, bytes_out, h->stream)); }
-    if (any_dba) { Prof pf(h, "k_dba_resolve"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), bytes_out, 1, h->stream)); }
+      HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, slots, static_cast<int64_t *>(h->scratch.p), doff, h->stream)); }
+    HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
+    h->plan.active = true; h->plan.any_plain = any_plain; h->plan.any_dict_enc = any_dict_enc; h->plan.any_dlba = any_dlba;
+    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots;
+    if ((rc = launch_byte_copies(h))) return rc;
     if (nullable) {
       const int n_tiles = (int)((slots + 1 + 4095) / 4096);
-      if ((rc = h->scratch.ensure(8 * (size_t)n_tiles + 64))) return rc;
       Prof pf(h, "k_scatter_offsets");
       HIP_TRY(launch_scatter_rank(static_cast<const int32_t *>(h->def.p), slots, col->max_def, static_cast<int64_t *>(h->scratch.p), n_tiles, h->stream));
       HIP_TRY(launch_scatter_offsets(static_cast<const int32_t *>(h->def.p), slots, col->max_def, static_cast<const int64_t *>(h->scratch.p), doff,
                                      static_cast<int64_t *>(h->offsets.p), h->stream));
     }
   } else {
-  if (dict_page >= 0) {
-    if (h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN && h->h_pages[(size_t)dict_page].encoding != PQD_ENC_PLAIN_DICTIONARY) {
-      // the reference decodes every dictionary page as PLAIN whatever its header says (layout/page.go:802)
-    }
-    if (col->physical_type == PQD_BOOLEAN) { g_last_error = "BOOLEAN dictionary pages are not implemented"; return PQD_ERR_UNSUPPORTED_TYPE; }
-    Prof pf(h, "k_dict_plain_fixed");
-    HIP_TRY(launch_dict_plain_fixed(c, dict_page, static_cast<uint8_t *>(h->dict.p), h->stream));
-  }
-  if (any_dict_enc) {
-    if (dict_page < 0) { host_status = host_status ? host_status : PQD_ERR_NO_DICTIONARY; }
-    else {
-      if (direct_rle && (esz == 4 || esz == 8)) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out, h->stream)); }
-      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
+    // every dictionary page is decoded as PLAIN whatever its header says (layout/page.go:802)
+    if (n_dict) { Prof pf(h, "k_dict_plain_fixed"); HIP_TRY(launch_dict_plain_fixed(c, d_dictp, n_dict, static_cast<uint8_t *>(h->dict.p), h->stream)); }
+    if (any_dict_enc || any_rle) {
+      if (direct_rle && any_dict_enc && (esz == 4 || esz == 8)) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c, static_cast<const uint8_t *>(h->dict.p), dense_out, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);
-        HIP_TRY(launch_expand_dict(c, d_tp_dc, d_ts_dc, tp_dict.back(), stage_dict, static_cast<const uint8_t *>(h->dict.p), dict_n, dense_out,
-                                   static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, shared_gpu && heavy == h->stream, heavy)); }
+        if ((rc = expand_dict_groups(c, static_cast<const uint8_t *>(h->dict.p), esz, dense_out))) return rc; }
       HIP_TRY(from_heavy());
     }
-  }
-  // a nullable column of PLAIN pages only: the scatter takes the values from the pages
-  const bool plain_scatter = nullable && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_other &&
-                             (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
-                              col->physical_type == PQD_DOUBLE) && std::getenv("PQD_NO_PLAIN_SCATTER") == nullptr;
-  if (any_plain && !plain_scatter) {
-    if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-    else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-  }
-  if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-  if (any_delta) {
-    if (col->physical_type != PQD_INT32 && col->physical_type != PQD_INT64) {
-      host_status = host_status ? host_status : PQD_ERR_UNSUPPORTED_ENCODING;  // layout/page.go:682
-    } else {
-      Prof pf(h, "k_delta_decode");
-      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, h->stream));
+    // a nullable column of PLAIN pages only: the scatter takes the values from the pages
+    const bool plain_scatter = nullable && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_rle && host_status == PQD_OK &&
+                               (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
+                                col->physical_type == PQD_DOUBLE) && h->opt[PQD_OPT_PLAIN_SCATTER] != 0;
+    if (any_plain && !plain_scatter) {
+      if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+      else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     }
-  }
-  if (any_other && host_status == PQD_OK) {
-    for (int p = 0; p < n_pages; p++) {
-      const PageIn &pi = h->h_pages[(size_t)p];
-      if (pi.data_idx < 0) continue;
-      const int e = pi.encoding;
-      if (!is_dict_enc(e) && e != PQD_ENC_PLAIN && e != PQD_ENC_DELTA_BINARY_PACKED && !(e == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
-        host_status = PQD_ERR_UNSUPPORTED_ENCODING; host_bad = p; break;
-      }
+    if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+    if (any_delta) { Prof pf(h, "k_delta_decode"); HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, h->stream)); }
+    if (nullable && slots > 0) {
+      Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
+      if (plain_scatter)
+        HIP_TRY(launch_scatter_plain(c, static_cast<const int32_t *>(h->def.p), static_cast<uint8_t *>(h->values.p), slots,
+                                     static_cast<int64_t *>(h->scratch.p), h->stream));
+      else
+        HIP_TRY(launch_scatter_fixed(c, static_cast<const int32_t *>(h->def.p), static_cast<const uint8_t *>(h->dense.p),
+                                     static_cast<uint8_t *>(h->values.p), slots, static_cast<int64_t *>(h->scratch.p), h->stream));
     }
-  }
-  if (nullable && slots > 0) {
-    const int n_tiles = (int)((slots + 4095) / 4096);
-    if ((rc = h->scratch.ensure(12 * (size_t)n_tiles + 64))) return rc;
-    Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
-    if (plain_scatter)
-      HIP_TRY(launch_scatter_plain(c, static_cast<const int32_t *>(h->def.p), static_cast<uint8_t *>(h->values.p), slots,
-                                   static_cast<int64_t *>(h->scratch.p), h->stream));
-    else
-    HIP_TRY(launch_scatter_fixed(c, static_cast<const int32_t *>(h->def.p), static_cast<const uint8_t *>(h->dense.p),
-                                 static_cast<uint8_t *>(h->values.p), slots, static_cast<int64_t *>(h->scratch.p), h->stream));
-  }
   }
   { Prof pf(h, "k_collect_status"); HIP_TRY(launch_collect_status(c, c.chunk_status, h->stream)); }
-  HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
+  if (!h->no_alloc) HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
 
   h->result = pqd_chunk_result{};
   h->result.status = host_status;
   h->result.bad_page = host_bad;
-  if (!h->busy) g_inflight.fetch_add(1, std::memory_order_relaxed);
-  h->busy = true;
+  set_busy(h, true);
   return PQD_OK;
+}
+
+// Completes the call in flight: totals, status, and for BYTE_ARRAY the byte copies once more when the output was
+// sized too small.
+int finish_call(pqd_handle *h) {
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->no_alloc) HIP_TRY(hipMemcpy(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost));
+  set_busy(h, false);
+  const int64_t *tot = static_cast<const int64_t *>(h->host_small.p);
+  const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + kSmallStatus;
+  pqd_chunk_result &r = h->result;
+  r.num_slots = tot[0]; r.num_values = tot[1]; r.num_nulls = tot[2]; r.num_rows = tot[3];
+  r.elem_size = h->elem_size;
+  r.has_levels = (h->col.max_def > 0 ? 1 : 0) | (h->col.max_rep > 0 ? 2 : 0);
+  // the first failing page in page order, whether the host or a kernel found it (a kernel's finding wins on the
+  // same page: what the page's own bytes do to the reference comes before what its caller does with the result)
+  if (r.status == PQD_OK) { r.status = st[0]; r.bad_page = st[1]; }
+  else if (st[0] != 0 && st[1] >= 0 && (r.bad_page < 0 || st[1] <= r.bad_page)) { r.status = st[0]; r.bad_page = st[1]; }
+  if (r.status == PQD_OK) r.bad_page = -1;
+  if (h->plan.active) {
+    const int64_t total = tot[kSmallByteTotal];
+    if (r.status == PQD_OK) {
+      if (total < 0 || total > ((int64_t)1 << 40)) { g_last_error = "implausible byte total"; r.status = PQD_ERR_MALFORMED; r.bad_page = 0; }
+      else if (total > (int64_t)h->bytes.cap - 64) {
+        int rc;
+        if ((rc = h->bytes.ensure((size_t)total + 64))) return rc;
+        if ((rc = launch_byte_copies(h))) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+      }
+      h->bytes_len = r.status == PQD_OK ? total : 0;
+    }
+  }
+  r.bytes_len = h->bytes_len;
+  h->have_result = true;
+  return PQD_OK;
+}
+
+// chunk bytes in host memory -> the handle's device input buffer through page-locked staging
+int stage_chunks(pqd_handle *h, int32_t n_chunks, const uint8_t *const *chunks, const size_t *lens, std::vector<int64_t> &chunk_off,
+                 size_t &span) {
+  chunk_off.resize((size_t)n_chunks);
+  size_t total = 0;
+  for (int k = 0; k < n_chunks; k++) {
+    if (lens[k] > 0 && !chunks[k]) return fail_arg("NULL chunk");
+    chunk_off[(size_t)k] = (int64_t)total;
+    total += align_up(lens[k] + 64, 256);
+  }
+  span = total;
+  int rc;
+  if ((rc = h->in.ensure(std::max<size_t>(total, 256)))) return rc;
+  // bytes the caller already put into one of the handle's input buffers are sent as they are
+  int k_in = -1;
+  if (n_chunks == 1 && lens[0] > 0)
+    for (int k = 0; k < 2; k++) if (chunks[0] == h->stage_in[k].p && h->stage_in[k].cap >= total) k_in = k;
+  const int s = k_in >= 0 ? k_in : h->stage_next;
+  if (k_in < 0) {
+    // the caller's memory may not be retained (cgo rule): copy into page-locked staging, then DMA.  Two staging
+    // buffers take turns, so this copy only ever waits for the transfer out of the same buffer two calls ago.
+    if (h->h2d_pending[s]) { HIP_TRY(hipEventSynchronize(h->ev_h2d[s])); h->h2d_pending[s] = false; }
+    if ((rc = h->stage_in[s].ensure(std::max<size_t>(total, 256)))) return rc;
+    h->stage_next = s ^ 1;
+  }
+  uint8_t *st = static_cast<uint8_t *>(h->stage_in[s].p);
+  for (int k = 0; k < n_chunks; k++) {
+    uint8_t *dst = st + chunk_off[(size_t)k];
+    if (k_in < 0 && lens[k]) std::memcpy(dst, chunks[k], lens[k]);
+    const size_t padded = align_up(lens[k] + 64, 256);
+    std::memset(dst + lens[k], 0, padded - lens[k]);
+  }
+  if (total) HIP_TRY(hipMemcpyAsync(h->in.p, st, total, hipMemcpyHostToDevice, h->stream));
+  if (h->ev_h2d[s] && hipEventRecord(h->ev_h2d[s], h->stream) == hipSuccess) h->h2d_pending[s] = true;
+  else HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
+int decode_host(pqd_handle *h, int32_t n_chunks, const uint8_t *const *chunks, const size_t *lens, const pqd_page_desc *pages,
+                const int32_t *pages_per_chunk, const pqd_column_desc *col, bool levels_only) {
+  if (!h || !col || n_chunks < 0 || (n_chunks > 0 && (!chunks || !lens || !pages_per_chunk))) return fail_arg("NULL argument");
+  if (h->no_alloc) return fail_arg("not a handle of this entry point");
+  Guard g(h->device);
+  if (h->busy) { HIP_TRY(hipStreamSynchronize(h->stream)); set_busy(h, false); }   // the device input buffer is about to be rewritten
+  std::vector<int32_t> first((size_t)n_chunks + 1, 0);
+  for (int k = 0; k < n_chunks; k++) {
+    if (pages_per_chunk[k] < 0 || first[(size_t)k] > 0x7FFFFFF0 - pages_per_chunk[k]) return fail_arg("bad page counts");
+    first[(size_t)k + 1] = first[(size_t)k] + pages_per_chunk[k];
+  }
+  if (first.back() > 0 && !pages) return fail_arg("NULL argument");
+  std::vector<int64_t> chunk_off;
+  size_t span = 0;
+  int rc;
+  if ((rc = stage_chunks(h, n_chunks, chunks, lens, chunk_off, span))) return rc;
+  return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), span, pages, first.back(), n_chunks, first.data(), chunk_off.data(), lens,
+                          col, levels_only);
+}
+
+int decode_device(pqd_handle *h, int32_t n_chunks, const void *const *d_chunks, const size_t *lens, const pqd_page_desc *pages,
+                  const int32_t *pages_per_chunk, const pqd_column_desc *col, bool levels_only) {
+  if (!h || !col || n_chunks < 0 || (n_chunks > 0 && (!d_chunks || !lens || !pages_per_chunk))) return fail_arg("NULL argument");
+  Guard g(h->device);
+  std::vector<int32_t> first((size_t)n_chunks + 1, 0);
+  std::vector<int64_t> chunk_off((size_t)n_chunks, 0);
+  uintptr_t lo = ~(uintptr_t)0, hi = 0;
+  for (int k = 0; k < n_chunks; k++) {
+    if (pages_per_chunk[k] < 0 || first[(size_t)k] > 0x7FFFFFF0 - pages_per_chunk[k]) return fail_arg("bad page counts");
+    first[(size_t)k + 1] = first[(size_t)k] + pages_per_chunk[k];
+    if (lens[k] > 0 && !d_chunks[k]) return fail_arg("NULL chunk");
+    if (lens[k] == 0) continue;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_chunks[k]);
+    if (a & 15u) return fail_arg("device chunk buffers must be 16-byte aligned");
+    lo = std::min(lo, a);
+    hi = std::max(hi, a + lens[k]);
+  }
+  if (first.back() > 0 && !pages) return fail_arg("NULL argument");
+  if (hi == 0) { lo = 0; }
+  for (int k = 0; k < n_chunks; k++) chunk_off[(size_t)k] = lens[k] ? (int64_t)(reinterpret_cast<uintptr_t>(d_chunks[k]) - lo) : 0;
+  return decode_on_device(h, reinterpret_cast<const uint8_t *>(lo), hi - lo, pages, first.back(), n_chunks, first.data(), chunk_off.data(), lens,
+                          col, levels_only);
 }
 
 }  // namespace
 
 extern "C" {
 
-const char *pqd_version(void) { return "pqdecode 0.1 (gfx950)"; }
+const char *pqd_version(void) { return "pqdecode 0.2 (gfx950)"; }
 const char *pqd_last_error(void) { return g_last_error.c_str(); }
 
 const char *pqd_strerror(int code) {
@@ -592,6 +835,7 @@ const char *pqd_strerror(int code) {
     case PQD_ERR_NO_DICTIONARY: return "dictionary-encoded page without a dictionary page";
     case PQD_ERR_THRIFT: return "page header could not be parsed";
     case PQD_ERR_REFUSED: return "malformed input the reference pads or reinterprets; refused";
+    case PQD_ERR_CAPACITY: return "output array of the caller too small: grow it and call again";
     default: return "unknown error";
   }
 }
@@ -606,6 +850,7 @@ int pqd_device_count(int *n_out) {
 }
 
 int pqd_handle_create(int device, void *stream, pqd_handle **out) {
+  PQD_GUARDED(
   if (!out) return fail_arg("out is NULL");
   *out = nullptr;
   int n = 0;
@@ -614,6 +859,7 @@ int pqd_handle_create(int device, void *stream, pqd_handle **out) {
   Guard g(device);
   pqd_handle *h = new pqd_handle();
   h->device = device;
+  for (int i = 0; i < PQD_OPT_COUNT; i++) h->opt[i] = defaults().opt[i];
   if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
   else {
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -622,25 +868,26 @@ int pqd_handle_create(int device, void *stream, pqd_handle **out) {
   }
   if (hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess) h->ev_ready = nullptr;
   if (hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) h->ev_done = nullptr;
+  for (int k = 0; k < 2; k++)
+    if (hipEventCreateWithFlags(&h->ev_h2d[k], hipEventDisableTiming) != hipSuccess) h->ev_h2d[k] = nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   *out = h;
   return PQD_OK;
+  )
 }
 
 int pqd_handle_destroy(pqd_handle *h) {
   if (!h) return PQD_OK;
   Guard g(h->device);
-  if (h->busy) { h->busy = false; g_inflight.fetch_sub(1, std::memory_order_relaxed); }
   (void)hipStreamSynchronize(h->stream);
+  set_busy(h, false);
   for (auto &e : h->events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
   if (h->ev_done) (void)hipEventDestroy(h->ev_done);
-  DevBuf *bufs[] = {&h->in, &h->meta, &h->runs, &h->tile_run, &h->dict, &h->values, &h->dense, &h->def, &h->rep,
-                    &h->offsets, &h->bytes, &h->scratch, &h->small, &h->pairs, &h->lens64, &h->prefix64, &h->parent,
-                    &h->doff, &h->dict_pairs, &h->tile_desc, &h->row_starts, &h->dba_flags};
-  for (DevBuf *b : bufs) b->release();
-  h->stage_in.release(); h->stage_out.release(); h->stage_meta.release(); h->host_small.release();
+  for (int k = 0; k < 2; k++) if (h->ev_h2d[k]) (void)hipEventDestroy(h->ev_h2d[k]);
+  for (DevBuf *b : h->all_bufs_) b->release();
+  h->stage_in[0].release(); h->stage_in[1].release(); h->stage_out.release(); h->stage_meta.release(); h->host_small.release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PQD_OK;
@@ -652,85 +899,90 @@ int pqd_set_profiling(pqd_handle *h, int on) {
   return PQD_OK;
 }
 
+int pqd_set_option(pqd_handle *h, int option, int value) {
+  if (!h) return fail_arg("handle is NULL");
+  if (option < 0 || option >= PQD_OPT_COUNT) return fail_arg("no such option");
+  h->opt[option] = value < 0 ? -1 : value;
+  return PQD_OK;
+}
+
 int pqd_decode_chunk_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
                             const pqd_column_desc *col) {
-  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !d_chunk)) return fail_arg("NULL argument");
-  Guard g(h->device);
-  return decode_on_device(h, static_cast<const uint8_t *>(d_chunk), len, pages, n_pages, col);
+  PQD_GUARDED(
+  if (n_pages < 0) return fail_arg("negative page count");
+  const void *chunks[1] = {d_chunk};
+  return decode_device(h, 1, chunks, &len, pages, &n_pages, col, false);
+  )
+}
+
+int pqd_decode_chunks_device(pqd_handle *h, int32_t n_chunks, const void *const *d_chunks, const size_t *lens, const pqd_page_desc *pages,
+                             const int32_t *pages_per_chunk, const pqd_column_desc *col, int32_t flags) {
+  PQD_GUARDED(
+  return decode_device(h, n_chunks, d_chunks, lens, pages, pages_per_chunk, col, (flags & PQD_LEVELS_ONLY) != 0);
+  )
 }
 
 int pqd_input_buffer(pqd_handle *h, size_t len, uint8_t **buf) {
+  PQD_GUARDED(
   if (!h || !buf) return fail_arg("NULL argument");
+  if (h->no_alloc) return fail_arg("not a handle of this entry point");
   Guard g(h->device);
   int rc;
-  if (h->busy) HIP_TRY(hipStreamSynchronize(h->stream));  // a decode in flight may still be reading the buffer
-  if ((rc = h->stage_in.ensure(align_up(len + 64, 256)))) return rc;
-  *buf = static_cast<uint8_t *>(h->stage_in.p);
+  const int s = h->stage_next;
+  if (h->h2d_pending[s]) { HIP_TRY(hipEventSynchronize(h->ev_h2d[s])); h->h2d_pending[s] = false; }  // a transfer may still be reading the buffer
+  if ((rc = h->stage_in[s].ensure(align_up(len + 64, 256)))) return rc;
+  h->stage_next = s ^ 1;
+  *buf = static_cast<uint8_t *>(h->stage_in[s].p);
   return PQD_OK;
+  )
 }
 
 int pqd_decode_chunk(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
                      const pqd_column_desc *col) {
-  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !chunk)) return fail_arg("NULL argument");
-  Guard g(h->device);
-  int rc;
-  const size_t padded = align_up(len + 64, 256);
-  if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
-  // the caller's memory may not be retained (cgo rule): copy into pinned staging, then DMA
-  if (chunk != h->stage_in.p) {                // (bytes already in the handle's input buffer are sent as they are)
-    HIP_TRY(hipStreamSynchronize(h->stream));  // the previous chunk may still be reading the staging buffer
-    std::memcpy(h->stage_in.p, chunk, len);
-  }
-  std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
-  HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
-  return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col);
+  PQD_GUARDED(
+  if (n_pages < 0) return fail_arg("negative page count");
+  const uint8_t *chunks[1] = {chunk};
+  return decode_host(h, 1, chunks, &len, pages, &n_pages, col, false);
+  )
+}
+
+int pqd_decode_chunks(pqd_handle *h, int32_t n_chunks, const uint8_t *const *chunks, const size_t *lens, const pqd_page_desc *pages,
+                      const int32_t *pages_per_chunk, const pqd_column_desc *col, int32_t flags) {
+  PQD_GUARDED(
+  return decode_host(h, n_chunks, chunks, lens, pages, pages_per_chunk, col, (flags & PQD_LEVELS_ONLY) != 0);
+  )
 }
 
 int pqd_decode_levels_device(pqd_handle *h, const void *d_chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
                              const pqd_column_desc *col) {
-  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !d_chunk)) return fail_arg("NULL argument");
-  Guard g(h->device);
-  return decode_on_device(h, static_cast<const uint8_t *>(d_chunk), len, pages, n_pages, col, true);
+  PQD_GUARDED(
+  if (n_pages < 0) return fail_arg("negative page count");
+  const void *chunks[1] = {d_chunk};
+  return decode_device(h, 1, chunks, &len, pages, &n_pages, col, true);
+  )
 }
 
 int pqd_decode_levels(pqd_handle *h, const uint8_t *chunk, size_t len, const pqd_page_desc *pages, int32_t n_pages,
                       const pqd_column_desc *col) {
-  if (!h || !col || n_pages < 0 || (n_pages > 0 && !pages) || (len > 0 && !chunk)) return fail_arg("NULL argument");
-  Guard g(h->device);
-  int rc;
-  const size_t padded = align_up(len + 64, 256);
-  if ((rc = h->in.ensure(padded)) || (rc = h->stage_in.ensure(padded))) return rc;
-  if (chunk != h->stage_in.p) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    std::memcpy(h->stage_in.p, chunk, len);
-  }
-  std::memset(static_cast<uint8_t *>(h->stage_in.p) + len, 0, padded - len);
-  HIP_TRY(hipMemcpyAsync(h->in.p, h->stage_in.p, padded, hipMemcpyHostToDevice, h->stream));
-  return decode_on_device(h, static_cast<const uint8_t *>(h->in.p), len, pages, n_pages, col, true);
+  PQD_GUARDED(
+  if (n_pages < 0) return fail_arg("negative page count");
+  const uint8_t *chunks[1] = {chunk};
+  return decode_host(h, 1, chunks, &len, pages, &n_pages, col, true);
+  )
 }
 
 int pqd_wait(pqd_handle *h, pqd_chunk_result *res) {
+  PQD_GUARDED(
   if (!h) return fail_arg("handle is NULL");
   Guard g(h->device);
   if (h->busy) {
-    h->busy = false;
-    g_inflight.fetch_sub(1, std::memory_order_relaxed);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    const int64_t *tot = static_cast<const int64_t *>(h->host_small.p);
-    const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + 16;
-    pqd_chunk_result &r = h->result;
-    r.num_slots = tot[0]; r.num_values = tot[1]; r.num_nulls = tot[2]; r.num_rows = tot[3];
-    r.bytes_len = h->bytes_len;
-    r.elem_size = h->elem_size;
-    r.has_levels = (h->col.max_def > 0 ? 1 : 0) | (h->col.max_rep > 0 ? 2 : 0);
-    if (r.status == PQD_OK) { r.status = st[0]; r.bad_page = st[1]; }
-    else if (st[0] != 0 && st[1] >= 0 && (r.bad_page < 0 || st[1] < r.bad_page)) { r.status = st[0]; r.bad_page = st[1]; }
-    if (r.status == PQD_OK) r.bad_page = -1;
-    h->have_result = true;
+    int rc = finish_call(h);
+    if (rc) { set_busy(h, false); return rc; }
   }
   if (!h->have_result) return fail_arg("no decode call to wait for");
   if (res) *res = h->result;
   return h->result.status;
+  )
 }
 
 int pqd_result_device(pqd_handle *h, pqd_device_result *out) {
@@ -771,8 +1023,10 @@ int pqd_copy_out(pqd_handle *h, void *values, int32_t *def_levels, int32_t *rep_
 }
 
 int pqd_result_host(pqd_handle *h, pqd_device_result *out) {
+  PQD_GUARDED(
   if (!h || !out) return fail_arg("NULL argument");
   if (!h->have_result) return fail_arg("no completed decode call");
+  if (h->no_alloc) return fail_arg("not a handle of this entry point");
   Guard g(h->device);
   *out = pqd_device_result{};
   const size_t n = (size_t)h->total_slots;
@@ -800,9 +1054,11 @@ int pqd_result_host(pqd_handle *h, pqd_device_result *out) {
   if (h->col.max_def > 0) out->def_levels = reinterpret_cast<int32_t *>(m + o_def);
   if (h->col.max_rep > 0) out->rep_levels = reinterpret_cast<int32_t *>(m + o_rep);
   return PQD_OK;
+  )
 }
 
 int pqd_row_starts(pqd_handle *h, int64_t *host_out, int64_t cap, int64_t **device_out) {
+  PQD_GUARDED(
   if (!h) return fail_arg("handle is NULL");
   if (!h->have_result) return fail_arg("no completed decode call");
   if (h->result.status != PQD_OK) return fail_arg("the last decode call failed");
@@ -819,9 +1075,11 @@ int pqd_row_starts(pqd_handle *h, int64_t *host_out, int64_t cap, int64_t **devi
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (device_out) *device_out = d;
   return PQD_OK;
+  )
 }
 
 int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages) {
+  PQD_GUARDED(
   if (!h || !out) return fail_arg("NULL argument");
   if (!h->have_result) return fail_arg("no completed decode call");
   Guard g(h->device);
@@ -836,6 +1094,7 @@ int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages) {
     out[3 * p + 2] = data ? std::max(h->h_pages[(size_t)p].num_values, 0) : 0;
   }
   return PQD_OK;
+  )
 }
 
 int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out) {

@@ -18,8 +18,14 @@ struct PageIn {
   int32_t num_values;
   int32_t rep_len;
   int32_t def_len;
-  int32_t data_idx;   // index among the chunk's data pages, -1 for a dictionary page
+  int32_t data_idx;   // index among the data pages of the call, -1 for a dictionary page
   int64_t slot_base;  // level slots of all earlier data pages
+  // The dictionary in effect: for a data page the last dictionary page before it in its chunk (ColumnBufferType keeps
+  // the latest one and drops it at the next row group, reader/columnbuffer.go:101, :132-135), -1 when there is none;
+  // for a dictionary page the page itself.
+  int32_t dict_page;
+  int32_t dict_n;     // entries of that dictionary
+  int64_t dict_off;   // its first entry in the handle's dictionary table (entries of all dictionary pages back to back)
 };
 
 // Device-side per-page state, filled by the kernels.

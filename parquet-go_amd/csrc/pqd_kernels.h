@@ -14,7 +14,8 @@ hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream);
 hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bool jump, hipStream_t stream);
 // dictionary-index streams made of one-byte-header RLE runs only (pages of up to 64 KiB, 4- or 8-byte entries) are
 // expanded straight from the page; they are marked and skipped by the prescan and the tile expansion
-hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict, int dict_n, uint8_t *values_out, hipStream_t stream);
+// (dict_table: the handle's dictionary table; every page looks its values up at its own PageIn.dict_off)
+hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict_table, uint8_t *values_out, hipStream_t stream);
 // the same for the repetition / definition level streams (streams [0, 2 nd)); counts nulls and row starts per page
 hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *def_out, hipStream_t stream);
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
@@ -25,13 +26,15 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
                                 hipStream_t stream);
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream);
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream);
-// dictionary indices -> gathered values
-hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
+// dictionary indices -> gathered values, for the tiles [tile_lo, tile_hi) (the data pages that share one dictionary;
+// `dict` points at its first entry; dict_n < 0: they have none and their indices pass through).  split_mode 0 / 1 pins the mid-size dictionary variant, -1 chooses by shared_gpu
+hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int tile_lo, int tile_hi,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, bool shared_gpu, hipStream_t stream);
+                              int n_cu, bool shared_gpu, int split_mode, hipStream_t stream);
 
 // ---- k_plain.hip ----
-hipError_t launch_dict_plain_fixed(const ChunkCtx &c, int dict_page, uint8_t *dict_out, hipStream_t stream);
+// dict_pages: device list of the call's dictionary pages (page indices)
+hipError_t launch_dict_plain_fixed(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint8_t *dict_out, hipStream_t stream);
 hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
                               hipStream_t stream);
 hipError_t launch_byte_stream_split(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
@@ -57,18 +60,20 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
                                hipStream_t stream);
 
 // ---- k_bytes.hip ----
-hipError_t launch_plain_ba_walk(const ChunkCtx &c, int which, uint64_t *pairs_out, hipStream_t stream);
+// dict_pages == nullptr: the PLAIN data pages; else the listed dictionary pages
+hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint64_t *pairs_out, hipStream_t stream);
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream);
 hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream);
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
                               hipStream_t stream);
+// The copies write nothing when the byte total (*total, on the device) exceeds cap, the capacity of bytes_out.
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
-                              hipStream_t stream);
+                              const int64_t *total, int64_t cap, hipStream_t stream);
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
-                                  hipStream_t stream);
+                                  const int64_t *total, int64_t cap, hipStream_t stream);
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
-                              int32_t *page_flag,
-                              uint8_t *bytes_out, int phase, hipStream_t stream);
+                              int32_t *page_flag, uint8_t *bytes_out, int phase, const int64_t *total, int64_t cap,
+                              hipStream_t stream);
 hipError_t launch_scatter_offsets(const int32_t *def, int64_t n_slots, int max_def, const int64_t *partial, const int64_t *doff,
                                   int64_t *slot_off, hipStream_t stream);
 

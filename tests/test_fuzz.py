@@ -50,11 +50,11 @@ def test_oracle_survives_malformed_chunks(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,variant", [(20240, None), (777000, "wave"), (31337, "wide")])
-def test_library_and_oracle_agree_on_malformed_chunks(oracle, seed, variant, monkeypatch):
+def test_library_and_oracle_agree_on_malformed_chunks(oracle, seed, variant):
     import parquet_go_amd as pq
-    if variant:
-        monkeypatch.setenv("PQD_PRESCAN", variant)   # both run-header walks see the malformed streams
     dec = pq.Decoder(0)
+    if variant:
+        dec.set_option(pq.binding.OPT_PRESCAN, 1 if variant == "wide" else 0)   # both run-header walks see the malformed streams
     bad, refused, other_kind = [], 0, []
     for name, chunk, pages, ptype, tl, md, mr in fuzzcases.cases(300, seed):
         o = oracle.read_chunk(chunk, pages, ptype, tl, md, mr)

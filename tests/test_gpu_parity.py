@@ -11,11 +11,20 @@ PHYS_DT = {pg.INT32: "<i4", pg.INT64: "<i8", pg.FLOAT: "<f4", pg.DOUBLE: "<f8"}
 
 
 @pytest.fixture(scope="module")
-def dec():
+def shared_dec():
     import parquet_go_amd as pq
     d = pq.Decoder(0)
     yield d
     d.close()
+
+
+@pytest.fixture
+def dec(shared_dec):
+    # one handle for the module (its work buffers are reused from test to test, as a reader reuses them from chunk
+    # to chunk); kernel-variant choices a test pins are handed back to the library afterwards
+    yield shared_dec
+    for opt in range(6):
+        shared_dec.set_option(opt, -1)
 
 
 def check_same(dec, oracle, chunk, pages, ptype, type_length=0, max_def=0, max_rep=0):
@@ -141,12 +150,12 @@ def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
 @pytest.mark.parametrize("direct", ["1", "0"])
 @pytest.mark.parametrize("ptype,w", [(pg.INT32, 32), (pg.INT64, 32), (pg.INT32, 9), (pg.DOUBLE, 1), (pg.BYTE_ARRAY, 32), (pg.INT96, 32),
                                      (pg.BYTE_ARRAY, 7)])
-def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, direct, monkeypatch):
+def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, direct):
     # index streams of one-byte-header RLE runs only (WriteRLE, encodingwrite.go:149-214) skip the run table when the
     # entries are 4 or 8 bytes wide; with nulls; a count that ends inside a run; and the pages that must stay on the
     # general path: a trailing byte, an empty run, a two-byte header, a bit-packed run, too few values; an index
     # beyond the dictionary
-    monkeypatch.setenv("PQD_DIRECT_RLE", direct)
+    dec.set_option(1, int(direct))           # PQD_OPT_DIRECT_RLE
     rng = np.random.default_rng(8100 + w + ptype)
     nd = min(1 << w, 300)
     nb = (w + 7) // 8
@@ -204,11 +213,11 @@ def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, d
 
 @pytest.mark.parametrize("variant", ["wave", "wide"])
 @pytest.mark.parametrize("w", [1, 2, 7, 8, 9, 16, 20, 32])
-def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant, monkeypatch):
+def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant):
     # long stretches of one-byte-header RLE runs (what WriteRLE emits, encodingwrite.go:149-172) broken up by runs of
     # 64 or more values (two-byte header), bit-packed runs and empty runs; pages whose count ends inside a stretch,
     # stretches that cross tile and window boundaries; levels written the same way
-    monkeypatch.setenv("PQD_PRESCAN", variant)
+    dec.set_option(0, 1 if variant == "wide" else 0)   # PQD_OPT_PRESCAN
     rng = np.random.default_rng(900 + w)
     nd = min(1 << w, 5000)
 
@@ -255,13 +264,13 @@ def test_dense_rle_stretches_taken_a_stride_at_a_time(dec, oracle, w, variant, m
 
 @pytest.mark.parametrize("jump", ["1", "0"])
 @pytest.mark.parametrize("w", [1, 2, 3, 5, 8, 9, 16, 20, 32])
-def test_short_runs_resolved_a_span_at_a_time(dec, oracle, w, jump, monkeypatch):
+def test_short_runs_resolved_a_span_at_a_time(dec, oracle, w, jump):
     # Arrow-style streams: a few values per run, bit-packed groups and RLE runs mixed, so that the headers follow no
     # fixed stride; now and then a run with a two-byte header, one long enough to leave the span or the window, an
     # empty run of either kind and a three-byte header (none of which the successor table covers); pages whose
     # count ends inside a span; the same as definition / repetition levels
-    monkeypatch.setenv("PQD_PRESCAN", "wave")
-    monkeypatch.setenv("PQD_JUMP", jump)
+    dec.set_option(0, 0)                     # PQD_OPT_PRESCAN: a wavefront per stream
+    dec.set_option(2, int(jump))             # PQD_OPT_JUMP
     rng = np.random.default_rng(4400 + w)
     nd = min(1 << w, 5000)
     nb = (w + 7) // 8
@@ -416,12 +425,12 @@ def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
 
 @pytest.mark.parametrize("copy_first", ["", "1"])
 @pytest.mark.parametrize("ptype", [pg.INT32, pg.INT64, pg.FLOAT, pg.DOUBLE])
-def test_nullable_plain_scattered_from_the_pages(dec, oracle, ptype, copy_first, monkeypatch):
+def test_nullable_plain_scattered_from_the_pages(dec, oracle, ptype, copy_first):
     # nullable column, PLAIN pages only: the scatter reads the value sections of the pages (no dense copy): many small
     # pages per 4096 slots, pages that are all null, pages without slots, a page boundary inside a thread's four
     # slots; then the same chunk with one page's value section a few bytes short (binaryread.go:12-18: ReadFull fails)
     if copy_first:
-        monkeypatch.setenv("PQD_NO_PLAIN_SCATTER", "1")
+        dec.set_option(3, 0)                 # PQD_OPT_PLAIN_SCATTER off
     rng = np.random.default_rng(6100 + ptype)
     esz = np.dtype(PHYS_DT[ptype]).itemsize
     for max_def, max_rep in ((1, 0), (3, 1)):
