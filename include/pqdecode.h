@@ -227,6 +227,22 @@ int pqd_decode_chunks_device(pqd_handle *h, int32_t n_chunks, const void *const 
                              const pqd_page_desc *pages, const int32_t *pages_per_chunk, const pqd_column_desc *col,
                              int32_t flags);
 
+/* pqd_decode_chunk_device for callers that cannot allocate (code under HIP graph capture rules, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  No handle: the work space is a fixed
+ * array of 32 MiB that every GPU the library runs on holds from load to process end, the outputs are the caller's
+ * device buffers, and the call makes no hipMalloc / hipFree / hipHostMalloc (host heap only, for the page table).
+ * Fixed-width physical types only (BYTE_ARRAY: PQD_ERR_INVALID_ARG).  d_values: num_slots * elem_size bytes
+ * (values_bytes says how many there are), d_def_levels / d_rep_levels: level_slots int32 each, NULL for a column
+ * without that level.  A chunk whose run tables, tile tables and (nullable columns) dense values do not fit the array
+ * returns PQD_ERR_NOMEM, outputs that are too small PQD_ERR_INVALID_ARG; nothing has been written then.  Synchronous:
+ * enqueues on `stream` (NULL: the default stream), waits for it and fills *res; returns the chunk's status.  Calls
+ * on one GPU share that GPU's array: they are serialised inside the library, and the array keeps no state between
+ * calls. */
+int pqd_decode_chunk_device_noalloc(int device, void *stream, const void *d_chunk, size_t len, const pqd_page_desc *pages,
+                                    int32_t n_pages, const pqd_column_desc *col, void *d_values, size_t values_bytes,
+                                    int32_t *d_def_levels, int32_t *d_rep_levels, size_t level_slots,
+                                    pqd_chunk_result *res);
+
 /* Wait for the handle's stream and collect status and totals.  Decode calls only enqueue work (BYTE_ARRAY columns
  * included: their byte output is sized from the page bytes, and a call whose strings need more - dictionary or
  * prefix expansion - has its copies redone here into a larger buffer). */

@@ -26,6 +26,7 @@ EXPORTS = [
     "pqd_input_buffer", "pqd_set_option", "pqd_decode_chunks", "pqd_decode_chunks_device",
     "pqd_footer_locate", "pqd_footer_parse", "pqd_footer_free", "pqd_footer_num_rows", "pqd_footer_num_row_groups",
     "pqd_footer_num_leaves", "pqd_footer_num_chunks", "pqd_footer_leaf", "pqd_footer_chunk",
+    "pqd_decode_chunk_device_noalloc",
 ]
 
 OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON = range(6)
@@ -98,6 +99,8 @@ def lib():
         L.pqd_decode_chunk_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
         L.pqd_decode_levels_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc)]
+        L.pqd_decode_chunk_device_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.POINTER(_ColDesc),
+                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_ChunkResult)]
         L.pqd_footer_locate.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
         L.pqd_footer_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.pqd_footer_free.argtypes = [C.c_void_p]
@@ -189,6 +192,19 @@ class Table:
         self.offsets = None
         self.bytes = None
         self.page_counts = None
+
+
+def decode_chunk_device_noalloc(device, stream, dev_ptr, nbytes, pages, physical_type, type_length, max_def, max_rep,
+                                values_ptr, values_bytes, def_ptr, rep_ptr, level_slots):
+    """pqd_decode_chunk_device_noalloc: every buffer is the caller's device memory.  -> (return code, _ChunkResult)"""
+    pg = np.ascontiguousarray(pages, dtype=PAGE_DESC_DTYPE)
+    cd = _ColDesc(physical_type, type_length, max_def, max_rep)
+    r = _ChunkResult()
+    rc = lib().pqd_decode_chunk_device_noalloc(device, C.c_void_p(stream) if stream else None, C.c_void_p(dev_ptr), nbytes,
+                                               C.c_void_p(pg.ctypes.data if pg.size else None), pg.size, C.byref(cd),
+                                               C.c_void_p(values_ptr), values_bytes, C.c_void_p(def_ptr) if def_ptr else None,
+                                               C.c_void_p(rep_ptr) if rep_ptr else None, level_slots, C.byref(r))
+    return rc, r
 
 
 class Decoder:

@@ -812,6 +812,44 @@ int decode_device(pqd_handle *h, int32_t n_chunks, const void *const *d_chunks, 
                           col, levels_only);
 }
 
+// ---- the entry point that allocates nothing ----
+// Work space of pqd_decode_chunk_device_noalloc: one array per GPU, held from the moment the library is loaded on it
+// until the process ends.  Host code never uses the array's name as an address: the address on each device comes
+// from hipGetSymbolAddress, once, and is what the kernels and copies get.
+constexpr size_t kNoAllocBytes = (size_t)32 << 20;
+__device__ __align__(256) unsigned char g_noalloc_scratch[kNoAllocBytes];
+
+struct NoAllocDevice {
+  std::mutex mu;          // calls on one GPU share its array: one at a time
+  bool ready = false;
+  Arena arena;
+  pqd_handle h;
+};
+NoAllocDevice g_noalloc[kMaxDevices];
+
+// with `device` current
+int noalloc_setup(NoAllocDevice &na, int device) {
+  if (na.ready) return PQD_OK;
+  void *ptr = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_noalloc_scratch)));
+  if (!ptr) return fail_arg("no address for the work space array");
+  na.arena.base = static_cast<uint8_t *>(ptr);
+  na.arena.cap = kNoAllocBytes;
+  na.arena.used = 0;
+  pqd_handle &h = na.h;
+  h.device = device;
+  h.no_alloc = true;
+  for (int i = 0; i < PQD_OPT_COUNT; i++) h.opt[i] = defaults().opt[i];
+  for (DevBuf *b : h.all_bufs_) b->arena = &na.arena;
+  for (DevBuf *b : {&h.values, &h.def, &h.rep}) { b->arena = nullptr; b->fixed = true; }
+  h.stage_meta.pageable = true;
+  h.host_small.pageable = true;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h.n_cu = prop.multiProcessorCount;
+  na.ready = true;
+  return PQD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -919,6 +957,33 @@ int pqd_decode_chunks_device(pqd_handle *h, int32_t n_chunks, const void *const 
                              const int32_t *pages_per_chunk, const pqd_column_desc *col, int32_t flags) {
   PQD_GUARDED(
   return decode_device(h, n_chunks, d_chunks, lens, pages, pages_per_chunk, col, (flags & PQD_LEVELS_ONLY) != 0);
+  )
+}
+
+int pqd_decode_chunk_device_noalloc(int device, void *stream, const void *d_chunk, size_t len, const pqd_page_desc *pages,
+                                    int32_t n_pages, const pqd_column_desc *col, void *d_values, size_t values_bytes,
+                                    int32_t *d_def_levels, int32_t *d_rep_levels, size_t level_slots, pqd_chunk_result *res) {
+  PQD_GUARDED(
+  if (!col || !res || n_pages < 0) return fail_arg("NULL argument");
+  if (device < 0 || device >= kMaxDevices) return fail_arg("no such device");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device >= n) return fail_arg("no such device");
+  Guard g(device);
+  NoAllocDevice &na = g_noalloc[device];
+  std::lock_guard<std::mutex> lk(na.mu);
+  int rc = noalloc_setup(na, device);
+  if (rc) return rc;
+  pqd_handle *h = &na.h;
+  h->stream = static_cast<hipStream_t>(stream);
+  h->values.p = d_values; h->values.cap = d_values ? values_bytes + 64 : 0;   // (the sizes asked for carry 64 bytes of slack that no kernel writes)
+  h->def.p = d_def_levels; h->def.cap = d_def_levels ? 4 * level_slots + 64 : 0;
+  h->rep.p = d_rep_levels; h->rep.cap = d_rep_levels ? 4 * level_slots + 64 : 0;
+  const void *chunks[1] = {d_chunk};
+  if ((rc = decode_device(h, 1, chunks, &len, pages, &n_pages, col, false))) return rc;
+  if ((rc = finish_call(h))) { set_busy(h, false); return rc; }
+  *res = h->result;
+  return h->result.status;
   )
 }
 
