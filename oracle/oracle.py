@@ -242,10 +242,9 @@ class ColumnBufferModel:
 
     def _read(self):
         if self.k >= len(self.tables):
-            if not self.eof:
-                self.eof = True
-                self.num_rows += 1      # columnbuffer.go:58
-            return False
+            self.eof = True
+            self.num_rows += 1          # columnbuffer.go:58, on every call past the last row group: a ReadRows on a
+            return False                # drained column therefore reports one row and hands out an empty table
         t = self.tables[self.k]
         self.k += 1
         self.rep = np.concatenate([self.rep, t.rep_levels])
@@ -264,6 +263,12 @@ class ColumnBufferModel:
         self.rep, self.dl = self.rep[end:], self.dl[end:]
         self.num_rows -= num
         return end, num
+
+
+    def skip_rows(self, num):
+        """reader/columnbuffer.go:194-230 as seen from outside: the rows SkipRows drops are the rows ReadRows would
+        have handed out (it reads the same pages, levels first, and pops the same table); -> (slots, rows) dropped."""
+        return self.read_rows(num)
 
 
 def read_chunk_timed(chunk, pages, physical_type, type_length=0, max_def=0, max_rep=0):
