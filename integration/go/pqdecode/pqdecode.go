@@ -1,13 +1,13 @@
 // Package pqdecode binds libpqdecode.so (include/pqdecode.h) for xitongsys/parquet-go.
 //
 // Source only: no Go toolchain exists in the image this library is built and tested in, so this file has not been
-// compiled there.  The Python ctypes mirror (parquet-go_amd/binding.py, parquet-go_amd/columnbuffer.py) makes the
-// same calls in the same order and is what the parity tests drive.
+// compiled there.  The Python ctypes mirror (parquet-go_amd/binding.py) makes the same calls in the same order and is
+// what the parity tests drive.
 //
-// Build:  CGO_CFLAGS=-I<repo>/include  CGO_LDFLAGS="-L<repo>/parquet-go_amd/lib -lpqdecode"  go build ./...
+// Build:  CGO_CFLAGS=-I<repo>/include  CGO_LDFLAGS="-L<repo>/parquet-go_amd/lib -lpqdecode"  go build -tags pqgpu ./...
 //
-// What it replaces: the per-page loop of reader.ColumnBufferType.ReadPage (reader/columnbuffer.go:105-156:
-// layout.ReadPage + Page.Decode + Table.Merge for every page) by one call per column chunk.
+// The package knows nothing of the reference's layout package (layout imports it, see ../layout_gpu): it hands
+// back Go slices - boxed values as encoding/encodingread.go produces them, int32 levels, per-page counts.
 package pqdecode
 
 /*
@@ -22,28 +22,26 @@ import (
 	"math"
 	"unsafe"
 
-	"github.com/xitongsys/parquet-go/layout"
 	"github.com/xitongsys/parquet-go/parquet"
 )
 
-// Handle is one HIP stream plus device workspaces; one per reader.ColumnBufferType, used by one goroutine at a
-// time (reader/reader.go:306-327 drives every column buffer from its own goroutine).
+// Handle is one HIP stream plus device workspaces, used by one goroutine at a time.
 type Handle struct{ h *C.pqd_handle }
 
 func NewHandle(device int) (*Handle, error) {
 	var h *C.pqd_handle
 	if rc := C.pqd_handle_create(C.int(device), nil, &h); rc != 0 {
-		return nil, libErr(rc, -1)
+		return nil, Err(int(rc), -1)
 	}
 	return &Handle{h}, nil
 }
 
 func (h *Handle) Close() { C.pqd_handle_destroy(h.h); h.h = nil }
 
-// libErr maps the library's codes onto the errors the reference's callers test for
+// Err maps the library's codes onto the errors the reference's callers test for
 // (io.EOF has meaning to ColumnBufferType.ReadPage, reader/columnbuffer.go:110).
-func libErr(code C.int, page C.int) error {
-	switch code {
+func Err(code int, page int) error {
+	switch C.int(code) {
 	case C.PQD_OK:
 		return nil
 	case C.PQD_ERR_EOF:
@@ -51,168 +49,184 @@ func libErr(code C.int, page C.int) error {
 	case C.PQD_ERR_UNEXPECTED_EOF:
 		return io.ErrUnexpectedEOF
 	case C.PQD_ERR_UNSUPPORTED_ENCODING:
-		return fmt.Errorf("Unknown Encoding method (page %d)", int(page)) // layout/page.go:716
+		return fmt.Errorf("Unknown Encoding method (page %d)", page) // layout/page.go:716
 	case C.PQD_ERR_UNSUPPORTED_PAGE_TYPE:
-		return fmt.Errorf("Unsupported page type (page %d)", int(page)) // layout/page.go:813
+		return fmt.Errorf("Unsupported page type (page %d)", page) // layout/page.go:813
 	default:
-		return fmt.Errorf("pqdecode: %s (page %d): %s", C.GoString(C.pqd_strerror(code)), int(page), C.GoString(C.pqd_last_error()))
+		return fmt.Errorf("pqdecode: %s (page %d): %s", C.GoString(C.pqd_strerror(C.int(code))), page, C.GoString(C.pqd_last_error()))
 	}
 }
 
 // Column is what layout.ReadPage takes from the schema handler and the column metadata for one leaf
 // (layout/page.go:797-805, :821-822, :897-900).
 type Column struct {
-	Path       []string
 	Type       parquet.Type
 	TypeLength int32
 	MaxDef     int32
 	MaxRep     int32
 }
 
-// DecodeChunk decodes all pages of one column chunk: chunk holds the chunk's bytes as they are in the file, from
-// the first page header on (reader/columnbuffer.go:89-99 gives the offset; MetaData.TotalCompressedSize the
-// length); the codec must be UNCOMPRESSED.  It returns the table ColumnBufferType.ReadPage would have merged
-// together page by page, and the number of row starts in it.
-//
-// chunk is copied into pinned staging inside pqd_decode_chunk, so no Go pointer is retained after the call
-// returns (the cgo pointer rule).
-func (h *Handle) DecodeChunk(chunk []byte, numValues int64, col Column) (*layout.Table, int64, error) {
-	t := layout.NewEmptyTable()
-	t.Path, t.MaxDefinitionLevel, t.MaxRepetitionLevel = col.Path, col.MaxDef, col.MaxRep
+// PageDesc is one parsed page header (pqd_page_desc).
+type PageDesc C.pqd_page_desc
+
+func (d *PageDesc) PageType() parquet.PageType { return parquet.PageType(d.page_type) }
+func (d *PageDesc) Encoding() parquet.Encoding { return parquet.Encoding(d.encoding) }
+func (d *PageDesc) NumValues() int32          { return int32(d.num_values) }
+func (d *PageDesc) Length() int32             { return int32(d.length) }
+
+// ScanPages walks the page headers of a chunk (pqd_scan_pages; layout.ReadPageHeader, layout/page.go:625-630), growing
+// the descriptor array when the chunk holds more pages than it has room for.
+func ScanPages(chunk []byte, numValues int64) ([]PageDesc, error) {
 	if len(chunk) == 0 {
-		return t, 0, nil
+		return nil, nil
 	}
-	p := (*C.uint8_t)(unsafe.Pointer(&chunk[0]))
-	descs := make([]C.pqd_page_desc, 64)
-	var n C.int32_t
+	descs := make([]PageDesc, 64)
 	for {
-		rc := C.pqd_scan_pages(p, C.size_t(len(chunk)), C.int64_t(numValues), &descs[0], C.int32_t(len(descs)), &n)
-		if rc == C.PQD_ERR_NOMEM { // more pages than descriptors: grow and walk again
-			descs = make([]C.pqd_page_desc, 4*len(descs))
+		var n C.int32_t
+		rc := C.pqd_scan_pages((*C.uint8_t)(unsafe.Pointer(&chunk[0])), C.size_t(len(chunk)), C.int64_t(numValues),
+			(*C.pqd_page_desc)(unsafe.Pointer(&descs[0])), C.int32_t(len(descs)), &n)
+		if rc == C.PQD_ERR_CAPACITY { // more pages than descriptors: grow and walk again
+			descs = make([]PageDesc, 4*len(descs))
 			continue
 		}
 		if rc != 0 {
-			return nil, 0, libErr(rc, C.int(n))
+			return nil, Err(int(rc), int(n))
 		}
-		break
+		return descs[:n], nil
 	}
-	cd := C.pqd_column_desc{physical_type: C.int32_t(col.Type), type_length: C.int32_t(col.TypeLength),
-		max_def: C.int32_t(col.MaxDef), max_rep: C.int32_t(col.MaxRep)}
-	if rc := C.pqd_decode_chunk(h.h, p, C.size_t(len(chunk)), &descs[0], n, &cd); rc != 0 {
-		return nil, 0, libErr(rc, -1)
-	}
-	var res C.pqd_chunk_result
-	if rc := C.pqd_wait(h.h, &res); rc != 0 {
-		return nil, 0, libErr(rc, -1)
-	}
-	if res.status != 0 {
-		return nil, 0, libErr(C.int(res.status), C.int(res.bad_page))
-	}
-	slots := int(res.num_slots)
-	t.DefinitionLevels = make([]int32, slots)
-	t.RepetitionLevels = make([]int32, slots)
-	t.Values = make([]interface{}, slots)
-	if slots == 0 {
-		return t, 0, nil
-	}
-	// The result is read in place from the handle's page-locked memory (valid until the handle's next decode call):
-	// the level arrays are copied into the Table, the values are boxed straight from it.
-	var hr C.pqd_device_result
-	if rc := C.pqd_result_host(h.h, &hr); rc != 0 {
-		return nil, 0, libErr(rc, -1)
-	}
-	if hr.def_levels != nil {
-		copy(t.DefinitionLevels, unsafe.Slice((*int32)(unsafe.Pointer(hr.def_levels)), slots))
-	}
-	if hr.rep_levels != nil {
-		copy(t.RepetitionLevels, unsafe.Slice((*int32)(unsafe.Pointer(hr.rep_levels)), slots))
-	}
-	if col.Type == parquet.Type_BYTE_ARRAY {
-		offs := unsafe.Slice((*int64)(unsafe.Pointer(hr.offsets)), slots+1)
-		buf := unsafe.Slice((*byte)(unsafe.Pointer(hr.bytes)), int(res.bytes_len))
-		for i := 0; i < slots; i++ {
-			if t.DefinitionLevels[i] == col.MaxDef {
-				t.Values[i] = string(buf[offs[i]:offs[i+1]]) // copies; the reference holds BYTE_ARRAY values as string
-			}
-		}
-		return t, int64(res.num_rows), nil
-	}
-	esz := int(res.elem_size)
-	raw := unsafe.Slice((*byte)(hr.values), slots*esz)
-	box(t, raw, esz, col)
-	return t, int64(res.num_rows), nil
 }
 
-// InputBuffer returns n bytes of the handle's page-locked input buffer.  A caller that reads the chunk from the file
-// straight into it (io.ReadFull(pFile, buf)) and passes the same slice to DecodeChunk saves one copy of the chunk;
-// the memory belongs to the library, so no Go pointer is involved.  Fill it only when the handle's previous
-// DecodeChunk has returned.
+// InputBuffer returns n bytes of one of the handle's page-locked input buffers.  A caller that reads the chunk from
+// the file straight into it and passes the same slice to Decode saves one copy of the chunk; the memory belongs to the
+// library, so no Go pointer is involved.
 func (h *Handle) InputBuffer(n int) ([]byte, error) {
 	var p *C.uint8_t
 	if rc := C.pqd_input_buffer(h.h, C.size_t(n), &p); rc != 0 {
-		return nil, libErr(rc, -1)
+		return nil, Err(int(rc), -1)
+	}
+	if n == 0 {
+		return nil, nil
 	}
 	return unsafe.Slice((*byte)(unsafe.Pointer(p)), n), nil
 }
 
-// box fills Table.Values with the boxed Go values the reference's decoders produce (encoding/encodingread.go:13-125:
+// PageCount is what layout.ReadPage returns for one data page besides its table (zeros for a dictionary page).
+type PageCount struct{ Nulls, Rows, Slots int64 }
+
+// Result is the merged table of the pages of one call, in Go memory.
+type Result struct {
+	Status  int // 0, or the code of the first failing page
+	BadPage int // index of that page among the descriptors of the call
+	Slots   int
+	Def     []int32
+	Rep     []int32
+	Values  []interface{} // nil where the definition level is below the maximum; nil slice after a levels-only call
+	Counts  []PageCount   // one per descriptor of the call
+}
+
+// Decode runs one call over the pages `descs` of `chunk` (any subset in page order; a dictionary page serves the
+// data pages behind it).  chunk is copied into page-locked staging inside the call unless it is the handle's input
+// buffer, so no Go pointer is retained (the cgo pointer rule).  A failing page is reported in Result.Status /
+// BadPage, not as an error.
+func (h *Handle) Decode(chunk []byte, descs []PageDesc, col Column, levelsOnly bool) (*Result, error) {
+	r := &Result{BadPage: -1}
+	if len(descs) == 0 {
+		return r, nil
+	}
+	var p *C.uint8_t
+	if len(chunk) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&chunk[0]))
+	}
+	cd := C.pqd_column_desc{physical_type: C.int32_t(col.Type), type_length: C.int32_t(col.TypeLength),
+		max_def: C.int32_t(col.MaxDef), max_rep: C.int32_t(col.MaxRep)}
+	dp := (*C.pqd_page_desc)(unsafe.Pointer(&descs[0]))
+	var rc C.int
+	if levelsOnly {
+		rc = C.pqd_decode_levels(h.h, p, C.size_t(len(chunk)), dp, C.int32_t(len(descs)), &cd)
+	} else {
+		rc = C.pqd_decode_chunk(h.h, p, C.size_t(len(chunk)), dp, C.int32_t(len(descs)), &cd)
+	}
+	if rc != 0 {
+		return nil, Err(int(rc), -1)
+	}
+	var res C.pqd_chunk_result
+	C.pqd_wait(h.h, &res)
+	if res.status == C.PQD_ERR_HIP || res.status == C.PQD_ERR_INVALID_ARG || res.status == C.PQD_ERR_NOMEM {
+		return nil, Err(int(res.status), -1)
+	}
+	r.Status, r.BadPage = int(res.status), int(res.bad_page)
+	if r.Status != 0 {
+		return r, nil
+	}
+	slots := int(res.num_slots)
+	r.Slots = slots
+	r.Def, r.Rep = make([]int32, slots), make([]int32, slots)
+	counts := make([]int64, 3*len(descs))
+	if rc := C.pqd_page_counts(h.h, (*C.int64_t)(unsafe.Pointer(&counts[0])), C.int32_t(len(descs))); rc != 0 {
+		return nil, Err(int(rc), -1)
+	}
+	r.Counts = make([]PageCount, len(descs))
+	for i := range r.Counts {
+		r.Counts[i] = PageCount{counts[3*i], counts[3*i+1], counts[3*i+2]}
+	}
+	if slots == 0 {
+		return r, nil
+	}
+	// The result is read in place from the handle's page-locked memory (valid until the handle's next decode call):
+	// the level arrays are copied out, the values are boxed straight from it.
+	var hr C.pqd_device_result
+	if rc := C.pqd_result_host(h.h, &hr); rc != 0 {
+		return nil, Err(int(rc), -1)
+	}
+	if hr.def_levels != nil {
+		copy(r.Def, unsafe.Slice((*int32)(unsafe.Pointer(hr.def_levels)), slots))
+	}
+	if hr.rep_levels != nil {
+		copy(r.Rep, unsafe.Slice((*int32)(unsafe.Pointer(hr.rep_levels)), slots))
+	}
+	if levelsOnly {
+		return r, nil
+	}
+	r.Values = make([]interface{}, slots)
+	if col.Type == parquet.Type_BYTE_ARRAY {
+		offs := unsafe.Slice((*int64)(unsafe.Pointer(hr.offsets)), slots+1)
+		buf := unsafe.Slice((*byte)(unsafe.Pointer(hr.bytes)), int(res.bytes_len))
+		for i := 0; i < slots; i++ {
+			if r.Def[i] == col.MaxDef {
+				r.Values[i] = string(buf[offs[i]:offs[i+1]]) // copies; the reference holds BYTE_ARRAY values as string
+			}
+		}
+		return r, nil
+	}
+	esz := int(res.elem_size)
+	box(r, unsafe.Slice((*byte)(hr.values), slots*esz), esz, col)
+	return r, nil
+}
+
+// box fills Result.Values with the boxed Go values the reference's decoders produce (encoding/encodingread.go:13-125:
 // bool, int32, int64, string of 12 bytes for INT96, float32, float64, string for FIXED_LEN_BYTE_ARRAY), nil where the
 // definition level is below the maximum (layout/page.go:905-923).
-func box(t *layout.Table, raw []byte, esz int, col Column) {
+func box(r *Result, raw []byte, esz int, col Column) {
 	le32 := func(b []byte) uint32 { return uint32(b[0]) | uint32(b[1])<<8 | uint32(b[2])<<16 | uint32(b[3])<<24 }
 	le64 := func(b []byte) uint64 { return uint64(le32(b)) | uint64(le32(b[4:]))<<32 }
-	for i := range t.Values {
-		if t.DefinitionLevels[i] != col.MaxDef {
+	for i := range r.Values {
+		if r.Def[i] != col.MaxDef {
 			continue
 		}
 		b := raw[i*esz : (i+1)*esz]
 		switch col.Type {
 		case parquet.Type_BOOLEAN:
-			t.Values[i] = b[0] != 0
+			r.Values[i] = b[0] != 0
 		case parquet.Type_INT32:
-			t.Values[i] = int32(le32(b))
+			r.Values[i] = int32(le32(b))
 		case parquet.Type_INT64:
-			t.Values[i] = int64(le64(b))
+			r.Values[i] = int64(le64(b))
 		case parquet.Type_FLOAT:
-			t.Values[i] = math.Float32frombits(le32(b))
+			r.Values[i] = math.Float32frombits(le32(b))
 		case parquet.Type_DOUBLE:
-			t.Values[i] = math.Float64frombits(le64(b))
+			r.Values[i] = math.Float64frombits(le64(b))
 		default: // INT96, FIXED_LEN_BYTE_ARRAY
-			t.Values[i] = string(b)
+			r.Values[i] = string(b)
 		}
 	}
-}
-
-// SkipLevels is the decode ColumnBufferType.SkipRows needs (reader/columnbuffer.go:194-230): levels and the row
-// count of the chunk, values left undecoded.
-func (h *Handle) SkipLevels(chunk []byte, numValues int64, col Column) (dls, rls []int32, numRows int64, err error) {
-	if len(chunk) == 0 {
-		return nil, nil, 0, nil
-	}
-	p := (*C.uint8_t)(unsafe.Pointer(&chunk[0]))
-	descs := make([]C.pqd_page_desc, 1+len(chunk)/64)
-	var n C.int32_t
-	if rc := C.pqd_scan_pages(p, C.size_t(len(chunk)), C.int64_t(numValues), &descs[0], C.int32_t(len(descs)), &n); rc != 0 {
-		return nil, nil, 0, libErr(rc, C.int(n))
-	}
-	cd := C.pqd_column_desc{physical_type: C.int32_t(col.Type), type_length: C.int32_t(col.TypeLength),
-		max_def: C.int32_t(col.MaxDef), max_rep: C.int32_t(col.MaxRep)}
-	if rc := C.pqd_decode_levels(h.h, p, C.size_t(len(chunk)), &descs[0], n, &cd); rc != 0 {
-		return nil, nil, 0, libErr(rc, -1)
-	}
-	var res C.pqd_chunk_result
-	if rc := C.pqd_wait(h.h, &res); rc != 0 {
-		return nil, nil, 0, libErr(rc, -1)
-	}
-	if res.status != 0 {
-		return nil, nil, 0, libErr(C.int(res.status), C.int(res.bad_page))
-	}
-	slots := int(res.num_slots)
-	dls, rls = make([]int32, slots), make([]int32, slots)
-	if slots > 0 {
-		if rc := C.pqd_copy_out(h.h, nil, (*C.int32_t)(unsafe.Pointer(&dls[0])), (*C.int32_t)(unsafe.Pointer(&rls[0])), nil, nil); rc != 0 {
-			return nil, nil, 0, libErr(rc, -1)
-		}
-	}
-	return dls, rls, int64(res.num_rows), nil
 }
