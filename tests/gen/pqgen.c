@@ -280,7 +280,7 @@ int32_t pqgen_list_chunk(uint64_t seed, int64_t n_slots, int64_t page_slots, uin
  * BYTE_ARRAY chunk of key-like strings: length U[8,64]; each string shares a prefix of U[0, len-1] bytes (capped by
  * the predecessor's length) with its predecessor inside the page and continues with random [a-z0-9].
  * mode 0: DELTA_LENGTH_BYTE_ARRAY (lengths, then the strings); mode 1: DELTA_BYTE_ARRAY (prefix lengths, then the
- * suffixes as DELTA_LENGTH_BYTE_ARRAY); mode 2: PLAIN (u32 length + bytes).
+ * suffixes as DELTA_LENGTH_BYTE_ARRAY); mode 2: PLAIN (u32 length + bytes); mode 3: DELTA_BYTE_ARRAY over sorted keys.
  */
 int64_t pqgen_strings_slot_bytes(int64_t page_values) { return (page_values * 70 + 4096 + 255) / 256 * 256; }
 
@@ -299,7 +299,23 @@ int32_t pqgen_strings_chunk(uint64_t seed, int64_t n_values, int64_t page_values
     uint8_t *str = (uint8_t *)malloc(64 * (size_t)nv);
     if (!lens || !pre || !str) { failed = 1; free(lens); free(pre); free(str); continue; }
     int64_t prev_len = 0;
-    for (int64_t i = 0; i < nv; i++) {
+    if (mode == 3) {
+      /* sorted keys: a 16-digit zero-padded counter that grows by U[1, 1000] from key to key, then U[0, 48] characters;
+       * every key shares its leading digits with its predecessor, so no prefix length inside a page is 0 */
+      uint64_t ctr = (uint64_t)pgi * (uint64_t)page_values * 1000ull;
+      for (int64_t i = 0; i < nv; i++) {
+        ctr += 1 + below(&s, 1000);
+        const int64_t len = 16 + (int64_t)below(&s, 49);
+        uint8_t *d = str + 64 * i;
+        uint64_t c = ctr;
+        for (int k = 15; k >= 0; k--) { d[k] = (uint8_t)('0' + c % 10); c /= 10; }
+        for (int64_t k = 16; k < len; k++) d[k] = (uint8_t)alpha[below(&s, 36)];
+        int64_t pl = 0;
+        if (i > 0) { const uint8_t *q = str + 64 * (i - 1); while (pl < len && pl < prev_len && q[pl] == d[pl]) pl++; }
+        lens[i] = len; pre[i] = pl; prev_len = len;
+      }
+    }
+    for (int64_t i = 0; i < nv && mode != 3; i++) {
       const int64_t len = 8 + (int64_t)below(&s, 57);
       int64_t pl = i == 0 ? 0 : (int64_t)below(&s, (uint64_t)len);
       if (pl > prev_len) pl = prev_len;
@@ -314,7 +330,7 @@ int32_t pqgen_strings_chunk(uint64_t seed, int64_t n_values, int64_t page_values
       enc = 6;
       p = delta_bp_encode(lens, nv, p);
       for (int64_t i = 0; i < nv; i++) { memcpy(p, str + 64 * i, (size_t)lens[i]); p += lens[i]; }
-    } else if (mode == 1) {
+    } else if (mode == 1 || mode == 3) {
       enc = 7;
       p = delta_bp_encode(pre, nv, p);
       for (int64_t i = 0; i < nv; i++) lens[i] -= pre[i];
