@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--list-slots", type=int, default=128 << 20)
     ap.add_argument("--string-values", type=int, default=100_000_000)
     ap.add_argument("--row-groups", type=int, default=1024, help="configs[4]: row groups of 1 Mi level slots over all GPUs")
+    ap.add_argument("--only-extra", type=str, default="", help="comma separated names: run only these extras (development aid)")
     ap.add_argument("--iso-reps", type=int, default=3, help="serial launches per width for the isolated kernel durations")
     return ap.parse_args()
 
@@ -362,6 +363,10 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
     from gen import pqgen
     extra = {}
     solo = rank == 0    # single-GPU extras run on rank 0 only; the scaling legs run on every rank
+    only = set(x for x in args.only_extra.split(",") if x)
+
+    def wanted(name):
+        return not only or name in only
 
     def timed_device(chunk, pages, ptype, max_def=0, max_rep=0, reps=3, dev=None):
         dev = to_device(chunk) if dev is None else dev
@@ -385,6 +390,8 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
     for esz, name, ptype in ((8, "delta_int64", pq.INT64), (4, "delta_int32", pq.INT32)):
         if not solo:
             break
+        if not wanted(name):
+            continue
         try:
             n = args.delta_values
             chunk, pages = pqgen.delta_chunk(0x5EED0003, n, 12, 128 << 10, esz) if esz == 8 else \
@@ -411,7 +418,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
             extra[name] = {"error": repr(ex)}
 
     # ---- PLAIN INT64: the copy-rate reference point ----
-    if solo:
+    if solo and wanted("plain_int64"):
         try:
             n = 256 << 20
             vals = np.arange(n, dtype=np.int64)
@@ -430,7 +437,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
 
     # ---- configs[0]-shaped: what the reference's own writer produces (layout/dictpage.go:155-158,
     # encodingwrite.go:183-214): dictionary indices at width 32 as RLE runs only, pages of about 8 KiB ----
-    if solo:
+    if solo and wanted("parquet_go_written"):
         try:
             n = 64 << 20
             chunk, pages = pqgen.dict_chunk(0x5EED0007, n, 32, 4096, 2048, 1, 2)
@@ -469,7 +476,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
             extra["parquet_go_written"] = {"error": repr(ex)}
 
     # ---- configs[4]: nested levels (optional list of optional int64), PLAIN values, one merged chunk ----
-    if solo:
+    if solo and wanted("list_int64"):
         try:
             n = args.list_slots
             chunk, pages = pqgen.list_chunk(0x5EED0005, n, 128 << 10)
@@ -495,6 +502,8 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
     for mode, name in ((0, "delta_length_byte_array"), (1, "delta_byte_array"), (3, "delta_byte_array_sorted_keys")):
         if not solo:
             break
+        if not wanted(name):
+            continue
         try:
             n = args.string_values
             chunk, pages = pqgen.strings_chunk(0x5EED0004, n, 64 << 10, mode)
@@ -524,6 +533,8 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
     # ---- strong-scaling legs: a fixed set of row-group chunks dealt over the ranks (sharding.assign_chunks), every
     # rank decoding its share; time = MAX over ranks.  Each rank generates only its own chunks. ----
     def strong_leg(name, n_chunks, make, decode_args, out_bytes_of, group, describe):
+        if not wanted(name):
+            return
         try:
             sizes = [1] * n_chunks
             mine = sharding.my_chunks(sizes, rank, world)
@@ -571,7 +582,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
                "PLAIN values; output = rep + def + slot-aligned values" % args.row_groups)
 
     # ---- host to host ----
-    if solo:
+    if solo and wanted("host_to_host"):
         try:
             n = 64 << 20
             chunk, pages = pqgen.dict_chunk(0x5EED0009, n, 12, 4096, 1 << 20)

@@ -129,7 +129,7 @@ int pqd_set_profiling(pqd_handle *h, int on);
 
 /* Kernel-variant choices of a handle.  Results never depend on them; tests pin each variant with them.  value -1
  * returns a choice to the library.  New handles start from the environment (read once per process):
- * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1. */
+ * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_DELTA_BLOCKS=0|1. */
 enum {
   PQD_OPT_PRESCAN = 0,        /* run-header walk: 0 a wavefront per stream, 1 a workgroup per stream */
   PQD_OPT_DIRECT_RLE = 1,     /* 0 / 1: expansion of RLE-only pages straight from the page */
@@ -137,7 +137,8 @@ enum {
   PQD_OPT_PLAIN_SCATTER = 3,  /* 0 / 1: nullable PLAIN columns scattered straight from the pages */
   PQD_OPT_SPLIT = 4,          /* 0 / 1: head of a mid-size dictionary kept in LDS */
   PQD_OPT_POISON = 5,         /* 1: every work and output buffer is filled with 0xFF before each call (debugging aid) */
-  PQD_OPT_COUNT = 6
+  PQD_OPT_DELTA_BLOCKS = 6,   /* 0 / 1: DELTA_BINARY_PACKED streams decoded block-parallel from a table of block starts */
+  PQD_OPT_COUNT = 7
 };
 int pqd_set_option(pqd_handle *h, int option, int value);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "pqd_decode_chunk_device_noalloc",
 ]
 
-OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON = range(6)
+OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON, OPT_DELTA_BLOCKS = range(7)
 LEVELS_ONLY = 1
 ERR_CAPACITY = -14
 

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   if (c.pages[p].encoding != encoding) return;
   const int64_t cnt = ps->cnt;
   if (ps->status != 0 || cnt <= 0) return;  // cnt == 0: ReadDataPageValues returns before reading
+  if (ps->delta_fast == 1) return;          // decoded block-parallel
 
   const int64_t src_off = src_sel ? ps->aux0 : ps->val_off;
   const uint8_t *abs0 = c.in + src_off;
@@ -389,8 +390,576 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   }
 }
 
-hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------
+// Block-parallel path for streams of the standard geometry (128-value blocks, 4 miniblocks) that are intact.
+//
+// k_delta_blocks (one wavefront per page) walks the block headers and leaves one DeltaBlock per block.  The chain -
+// a block's length follows from its own widths - is followed 64 blocks at a time: every lane parses the header that
+// sits where block j would start if all blocks were as long as the last one seen; the leading lanes whose
+// predecessors all have that length are at true block starts (exact: the first block of another length ends the
+// step, and its length is the next guess).  Streams of steady width - timestamps, counters, lengths - take one step
+// per 64 blocks.  Anything unusual (another geometry, a header cut by the end of the stream, a miniblock that runs
+// past it, a count that contradicts the page) leaves the page to k_delta_decode, which reproduces the reference's
+// behaviour on such input; delta_fast tells the two apart.
+//
+// The blocks of a page are then cut into units of 32 (4096 values), one wavefront each (k_delta_units).  The only
+// thing that ties a block to the ones before it is the running value.  A unit stages its packed bytes in LDS (one
+// coalesced sweep; the loop that follows has no global loads, so its stores are never waited for), adds up the
+// deltas of every block - one block per lane, fields peeled off a bit buffer - and publishes the unit's total; it
+// then collects the totals of the units before it in the page (they were started no later and publish before they
+// wait, so the wait is short; it is bounded all the same, and a page whose wait ran out is decoded again by
+// k_delta_decode) and decodes two blocks per step with nothing carried from step to step: four consecutive values
+// per lane from four LDS dwords, a lane-local running sum, one scan over the 32 lanes of a block, 16 or 32 bytes of
+// output per lane.  The packed bytes are read from memory once.
+//
+// Work space: DeltaBlock[nb] | unit totals 2 x uint64[nu] | DeltaUnit[nu], with
+// nb = slots / 128 + 3 * pages + 8 and nu = slots / 4096 + pages + 8.  Per page the block table holds n_blocks
+// entries, then {first value (min_delta field)} and {stream start (min_delta field)}.
+// ---------------------------------------------------------------------------------------------
+struct DeltaWork {
+  DeltaBlock *blocks;
+  uint64_t *gsum;       // two words per unit: the unit's total, published by the unit itself
+  DeltaUnit *units;
+  int64_t n_units;
+};
+
+__device__ __forceinline__ int64_t delta_table_base(const PageIn &pi) { return (pi.slot_base >> 7) + 3 * (int64_t)pi.data_idx; }
+__device__ __forceinline__ int64_t delta_unit_base(const PageIn &pi) { return (pi.slot_base >> (7 + 5)) + (int64_t)pi.data_idx; }   // (7 + kUnitShift)
+
+// -> the number of blocks, or -1 when the page is left to k_delta_decode
+__device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int lane,
+                                              int64_t *src_off_out, uint64_t *first_out) {
+  if (lane == 0) ps->delta_fast = 0;
+  const int64_t cnt = ps->cnt;
+  if (ps->status != 0 || cnt <= 0) return -1;
+  const int64_t src_off = src_sel ? ps->aux0 : ps->val_off;
+  const int64_t slen = ps->val_off + ps->val_len - src_off;
+  if (slen <= 0 || slen > 0x7FFFFF00ll) return -1;
+  const uint8_t *src = c.in + src_off;
+  const uint32_t end = (uint32_t)slen;
+  // stream header: four varints, parsed by every lane alike
+  uint32_t q = 0;
+  uint64_t hdr[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint64_t v = 0;
+    uint32_t shift = 0;
+    for (int n = 0; n < 10; n++) {
+      if (q >= end) return -1;                   // a header cut short: the general path
+      const uint32_t b = src[q++];
+      if (shift < 64) v |= (uint64_t)(b & 0x7Fu) << shift;
+      if ((b & 0x80u) == 0) break;
+      shift += 7;
+      if (n == 9) return -1;
+    }
+    hdr[i] = v;
+  }
+  if (hdr[0] != 128 || hdr[1] != 4) return -1;
+  const uint64_t n_values = hdr[2];
+  const int64_t nv_page = pi.num_values > 0 ? pi.num_values : 0;
+  if (n_values < (uint64_t)cnt || n_values > (uint64_t)nv_page) return -1;       // (short: an error; long: no room in the table)
+  if (pi.encoding != PQD_ENC_DELTA_BINARY_PACKED && n_values != (uint64_t)cnt) return -1;
+  const uint32_t n_blocks = (uint32_t)((n_values - 1 + 127) / 128);
+  DeltaBlock *tb = table + delta_table_base(pi);
+  const uint8_t *in_last = c.in + ((c.in_len + 3) & ~(int64_t)3) - 4;             // last dword that may be read
+
+  uint32_t pos = q, guess = 0;
+  uint32_t b0 = 0;
+  while (b0 < n_blocks) {
+    const uint32_t blk = b0 + (uint32_t)lane;
+    const uint64_t pj64 = (uint64_t)pos + (uint64_t)lane * guess;
+    const bool mine = blk < n_blocks && (lane == 0 || guess != 0) && pj64 + 5 <= end;
+    uint32_t size = 0, data_off = 0, widths = 0, dbytes = 0;
+    uint64_t md = 0;
+    bool good = false;
+    if (mine) {
+      const uint32_t pj = (uint32_t)pj64;
+      // 16 bytes at pj (aligned dwords, clamped at the end of the buffer: bytes past the stream are never looked at)
+      const uint8_t *a0 = src + pj;
+      const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
+      const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);
+      const uint32_t *wl = reinterpret_cast<const uint32_t *>(in_last);
+      uint32_t dw[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) dw[i] = *(w0 + i <= wl ? w0 + i : wl);
+      uint32_t x[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], al * 8u);
+      // minimum delta: a varint of at most 10 bytes
+      uint32_t hl = 0, shift = 0;
+      bool closed = false;
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        if (!closed) {
+          const uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+          hl++;
+          if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
+          shift += 7;
+          closed = (b & 0x80u) == 0;
+        }
+      }
+      if (closed && (uint64_t)pj + hl + 4 <= end) {
+        const uint64_t x64lo = ((uint64_t)x[1] << 32) | x[0], x64hi = ((uint64_t)x[3] << 32) | x[2];
+        const uint32_t wb = hl < 8 ? (uint32_t)((x64lo >> (8u * hl)) | (hl ? x64hi << (64u - 8u * hl) : 0ull)) : (uint32_t)(x64hi >> (8u * (hl - 8u)));
+        // miniblocks the stream still needs at this block (encodingread.go:372: reading stops with the count)
+        const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
+        const int need = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
+        uint32_t bytes = 0, wmax = 0;
+        widths = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
+          if (m < need) { bytes += 4u * wm; widths |= wm << (8 * m); wmax = wm > wmax ? wm : wmax; }
+        }
+        data_off = pj + hl + 4u;
+        dbytes = bytes;
+        size = hl + 4u + bytes;
+        good = wmax <= 64u && (uint64_t)data_off + bytes <= end;
+      }
+    }
+    // lane j sits at a true block start when every lane before it is good and as long as the guess
+    const uint64_t okm = __ballot(good && size == guess);
+    const uint64_t goodm = __ballot(good);
+    const int n_chain = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);   // lanes [0, n_chain) continue the chain at the guessed length
+    // the lane after them is at a true start too (its own length may differ)
+    int n_true = n_chain < 64 ? n_chain + 1 : 64;
+    if (guess == 0) n_true = 1;
+    if (b0 + (uint32_t)n_true > n_blocks) n_true = (int)(n_blocks - b0);
+    const uint64_t want = n_true >= 64 ? ~0ull : ((1ull << n_true) - 1);
+    if ((goodm & want) != want) return -1;       // a block the fast path does not take
+    if (lane < n_true) {
+      tb[blk] = DeltaBlock{data_off, widths, md};
+      // the byte range of the unit the block belongs to
+      if ((blk & 31u) == 0u) pu[blk >> 5].win_start = data_off;                                   // (kUnitBlocks = 32)
+      if ((blk & 31u) == 31u || blk + 1u == n_blocks) pu[blk >> 5].win_end = data_off + dbytes;
+    }
+    const int last = n_true - 1;
+    const uint32_t pos_last = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)pj64), last);
+    const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)size, last);
+    pos = pos_last + size_last;
+    guess = size_last;
+    b0 += (uint32_t)n_true;
+  }
+  if (lane == 0) {
+    tb[n_blocks] = DeltaBlock{0u, 0u, hdr[3]};
+    tb[n_blocks + 1] = DeltaBlock{0u, 0u, (uint64_t)src_off};
+    ps->aux0 = src_off + (int64_t)pos;   // where the delta stream ended (start of a byte-array payload)
+    ps->aux1 = (int64_t)n_values;
+    ps->delta_fast = 1;
+  }
+  *src_off_out = src_off;
+  *first_out = hdr[3];
+  return (int64_t)n_blocks;
+}
+
+__global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, int src_sel, DeltaWork w) {
+  const int lane = threadIdx.x;
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  const PageIn &pi = c.pages[p];
+  const int64_t nvp = pi.num_values > 0 ? pi.num_values : 0;
+  const int64_t ub = delta_unit_base(pi);
+  const int64_t range = ((pi.slot_base + nvp) >> 12) - (pi.slot_base >> 12) + 1;
+  int64_t src_off = 0;
+  uint64_t first_raw = 0;
+  const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, lane, &src_off, &first_raw) : -1;
+  // the page's units: the ones its blocks fill get their records, the rest of its range holds nothing
+  const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + 31) / 32);     // (a stream of one value still has its first value to write)
+  for (int64_t j = lane; j < range; j += 64) {
+    if (ub + j >= w.n_units) continue;
+    DeltaUnit *r = w.units + ub + j;
+    if (j < ng) {
+      r->g = (uint32_t)j; r->n_blocks = (uint32_t)nb; r->spare = 0;
+      r->tbase = delta_table_base(pi); r->src_off = src_off; r->out_base = c.state[p].dense_base; r->cnt = c.state[p].cnt;
+      r->first_raw = first_raw;
+      r->page = p;
+    } else {
+      r->page = -1;
+    }
+    w.gsum[2 * (ub + j)] = 0;
+    w.gsum[2 * (ub + j) + 1] = 0;
+  }
+}
+
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // a value every lane holds alike, moved to scalar registers
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int kUnitShift = 5;            // a unit is 32 blocks = 4096 values
+constexpr uint32_t kUnitBlocks = 1u << kUnitShift;
+constexpr int kWinBytes = 8192;         // LDS window over the packed bytes of a unit
+constexpr int kWinSlack = 64;           // bytes past the window that a lane's last reads may touch (never used)
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+// Totals are published as self-validating 64-bit words (bit 32 set, 32 bits of the total below it), written and
+// polled with device-scope atomics: no fence is needed and a word is either absent or whole.
+__device__ __forceinline__ void publish_word(uint64_t *slot, uint32_t v) {
+  __hip_atomic_store(slot, (1ull << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both words of a unit (one for 32-bit values), asked for back to back
+template <bool TWO>
+__device__ __forceinline__ void poll_raw(const uint64_t *slot, uint64_t *a, uint64_t *b) {
+  *a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *b = TWO ? __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
+}
+__device__ __forceinline__ bool poll_word(const uint64_t *slot, uint32_t *v) {
+  const uint64_t x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *v = (uint32_t)x;
+  return (x >> 32) != 0;
+}
+
+// inclusive prefix sum over each half of the wavefront (the 32 lanes of one block), wrapping
+__device__ __forceinline__ uint32_t half_incl_scan(uint32_t x) {
+#pragma unroll
+  for (int n = 1; n <= 8; n <<= 1) x += dpp_row_shr(x, n);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // lane 15 of a row to the row after it, rows 1 and 3
+  return x;
+}
+__device__ __forceinline__ uint64_t half_incl_scan(uint64_t x) {
+#pragma unroll
+  for (int n = 1; n <= 8; n <<= 1) {
+    const uint32_t lo = dpp_row_shr((uint32_t)x, n), hi = dpp_row_shr((uint32_t)(x >> 32), n);
+    x += ((uint64_t)hi << 32) | lo;
+  }
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x142, 0xA, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x142, 0xA, 0xF, false);
+  return x + (((uint64_t)hi << 32) | lo);
+}
+
+// Sum of the 128 packed deltas of a full block (without the minimum delta), by one lane, from the LDS window.
+// r: byte offset of the block's first miniblock in the window.  A miniblock of width w is exactly w dwords.
+template <class T>
+__device__ __forceinline__ T delta_block_sum(const uint32_t *win, uint32_t r, uint32_t widths) {
+  T sum = 0;
+  const uint32_t al = (r & 3u) * 8u;
+  uint32_t di = r >> 2;
+  uint32_t cur = win[di];
+#pragma unroll 1
+  for (int m = 0; m < 4; m++) {
+    const uint32_t w = (widths >> (8 * m)) & 0xFFu;
+    if (w == 0) continue;
+    const uint64_t mask = w >= 64u ? ~0ull : ((1ull << w) - 1ull);
+    // a bit buffer of up to 127 bits in (hi:lo); one dword in, values out while enough bits are there
+    uint64_t lo = 0, hi = 0;
+    uint32_t nbits = 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < w; j++) {
+      const uint32_t nxt = win[di + 1];
+      const uint64_t dw = __builtin_amdgcn_alignbit(nxt, cur, al);
+      cur = nxt;
+      di++;
+      if (nbits < 64u) { lo |= dw << nbits; if (nbits > 32u) hi |= dw >> (64u - nbits); }
+      else hi |= dw << (nbits - 64u);
+      nbits += 32u;
+      while (nbits >= w) {
+        sum += (T)(lo & mask);
+        if (w >= 64u) { lo = hi; hi = 0; }
+        else { lo = (lo >> w) | (hi << (64u - w)); hi >>= w; }
+        nbits -= w;
+      }
+    }
+  }
+  return sum;
+}
+
+// One wavefront per unit of 32 blocks: stage the packed bytes in LDS, add up every block's deltas, publish the unit's
+// total, collect the totals of the units before it in the page, decode two blocks per step.
+template <class T>
+__global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
+  __shared__ uint4 win4[(kWinBytes + kWinSlack) / 16];
+  __shared__ DeltaBlock s_ent[kUnitBlocks];
+  __shared__ uint64_t s_prev[kUnitBlocks];
+  __shared__ uint32_t s_tot[kUnitBlocks];
+  __shared__ uint4 s_stage[sizeof(T) == 8 ? 128 : 1];
+  uint32_t *win = reinterpret_cast<uint32_t *>(win4);
+  const int lane = threadIdx.x;
+  const int64_t u = blockIdx.x;
+  // the unit's record: sixteen dwords, one load
+  const uint32_t rv = reinterpret_cast<const uint32_t *>(w.units + u)[lane & 15];
+  auto r32 = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)rv, i); };
+  auto r64 = [&](int i) { return (int64_t)(((uint64_t)r32(i + 1) << 32) | r32(i)); };
+  const int p = (int)r32(0);
+  if (p < 0) return;
+  const uint32_t g = r32(1), n_blocks = r32(2), win_start = r32(3), win_end = r32(4);
+  const int64_t tbase = r64(6), cnt = r64(12);
+  const DeltaBlock *tb = w.blocks + tbase;
+  const T first = DeltaTraits<T>::zigzag((uint64_t)r64(14));
+  const uint8_t *src = c.in + r64(8);
+  const int64_t lim = (int64_t)((c.in + c.in_len) - src);          // bytes of the buffer from src on
+  const uint32_t src_al = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+  T *out = values_out + r64(10);
+  if (g == 0 && lane == 0) out[0] = first;
+  const uint32_t b0 = kUnitBlocks * g;
+  const uint32_t nb_here = b0 >= n_blocks ? 0u : (n_blocks - b0 < kUnitBlocks ? n_blocks - b0 : kUnitBlocks);
+
+  // one block per lane (of the first 32)
+  DeltaBlock E{0u, 0u, 0ull};
+  if ((uint32_t)lane < nb_here) E = tb[b0 + (uint32_t)lane];
+  // The unit's bytes, when the window holds them all, are asked for at once with the table entries (the record
+  // names the range); otherwise the window moves over the blocks.
+  uint32_t win_a0 = win_start - ((src_al + win_start) & 15u);
+  const bool one_window = nb_here != 0u && win_end - win_a0 <= (uint32_t)kWinBytes;
+  auto fill_window = [&](uint32_t a0, uint32_t end) {
+    // (a0 may lie up to 15 bytes in front of the stream: signed from here on)  All loads first, then the LDS writes.
+    constexpr int kSweeps = (kWinBytes + 1023) / 1024;
+    const int64_t o0 = (int64_t)(int32_t)a0 + 16 * lane;
+    uint4 x[kSweeps];
+#pragma unroll
+    for (int i = 0; i < kSweeps; i++) {
+      const int64_t o = o0 + 1024 * i;
+      x[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (o < (int64_t)end && o < lim) x[i] = *reinterpret_cast<const uint4 *>(src + o);   // (16-byte aligned; its granule holds bytes of the buffer)
+    }
+#pragma unroll
+    for (int i = 0; i < kSweeps; i++)
+      if (o0 + 1024 * i < (int64_t)end) win4[(uint32_t)(16 * lane + 1024 * i) >> 4] = x[i];
+  };
+  if (one_window) fill_window(win_a0, win_end);
+  const uint32_t wsum = (E.widths & 0xFFu) + ((E.widths >> 8) & 0xFFu) + ((E.widths >> 16) & 0xFFu) + (E.widths >> 24);
+  const uint32_t data_end = E.data_off + 4u * wsum;
+  if ((uint32_t)lane < kUnitBlocks) s_ent[lane] = E;
+  __syncthreads();
+
+  // Stage the bytes of blocks [bs, be) - as many as the window holds - and return be.  The window starts at the
+  // 16-byte boundary at or below the first block; every block has its bytes inside the stream (k_delta_blocks).
+  auto stage = [&](uint32_t bs) -> uint32_t {
+    const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)E.data_off, (int)bs);
+    const uint32_t a0 = start - ((src_al + start) & 15u);
+    const bool fits = (uint32_t)lane >= bs && (uint32_t)lane < nb_here && data_end - a0 <= (uint32_t)kWinBytes;
+    const uint64_t fm = __ballot(fits) >> bs;
+    uint32_t n = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
+    if (bs + n < nb_here) n &= ~1u;                 // steps take blocks in pairs
+    const uint32_t be = bs + n;                     // (n >= 2: two blocks of the widest kind are about 2 KiB)
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)data_end, (int)(be - 1u));
+    __syncthreads();                                // the window's previous readers are done
+    fill_window(a0, end);
+    __syncthreads();
+    win_a0 = a0;
+    return be;
+  };
+
+  // ---- the running value in front of every block of the unit ----
+  uint32_t be = one_window ? nb_here : (nb_here ? stage(0u) : 0u);
+  const bool wide_mine = ((((E.widths & 0x7F7F7F7Fu) + 0x67676767u) | E.widths) & 0x80808080u) != 0u;   // a width byte above 24
+  // The quick unit: one window holds it and no width exceeds 24 bits.  Then the sum of the packed deltas in front of
+  // any value of a block fits 32 bits.  A first sweep over the window - two blocks per step, four values per lane, as
+  // the values will be written - leaves every block's total in LDS and keeps nothing else, so that the unit's total
+  // goes out as early as possible; the second sweep, once the unit's starting value is known, unpacks again and
+  // stores.
+  const bool quick = nb_here != 0u && one_window && __ballot(wide_mine) == 0ull;
+  const int half = lane >> 5, m = (lane >> 3) & 3, k = lane & 7;
+  // step i of the quick sweeps: the running sums c[0..3] of this lane's four packed deltas
+  auto unpack4 = [&](int i, uint32_t (&cs)[4], uint32_t &blk_l, bool &live) {
+    blk_l = 2u * (uint32_t)i + (uint32_t)half;
+    live = blk_l < nb_here;
+    const uint32_t ei = live ? blk_l : 0u;
+    const uint32_t data_off = s_ent[ei].data_off, widths = s_ent[ei].widths;
+    const uint32_t wm = (widths >> (8 * m)) & 0xFFu;
+    const uint32_t pre = m ? ((widths * 0x01010101u) >> (8 * (m - 1))) & 0xFFu : 0u;   // widths of the miniblocks before this one
+    const uint32_t bit = 32u * pre + 4u * (uint32_t)k * wm;
+    const uint32_t r = data_off - win_a0 + (bit >> 3);
+    const uint32_t shift = (r & 3u) * 8u + (bit & 7u);
+    const uint32_t *q = win + (r >> 2);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+    const uint32_t g0 = __builtin_amdgcn_alignbit(d1, d0, shift), g1 = __builtin_amdgcn_alignbit(d2, d1, shift),
+                   g2 = __builtin_amdgcn_alignbit(d3, d2, shift);
+    const uint64_t lo = ((uint64_t)g1 << 32) | g0;
+    const uint32_t mask = (1u << wm) - 1u;
+    const uint32_t t2 = 2u * wm;
+    const uint64_t lo2 = (lo >> t2) | ((uint64_t)g2 << ((64u - t2) & 63u));
+    cs[0] = (uint32_t)lo & mask;
+    cs[1] = cs[0] + ((uint32_t)(lo >> wm) & mask);
+    cs[2] = cs[1] + ((uint32_t)lo2 & mask);
+    cs[3] = cs[2] + ((uint32_t)(lo2 >> wm) & mask);
+  };
+  T s = 0;
+  if (quick) {
+    // (four steps at a time without a branch between them, so that the LDS reads of one step overlap the arithmetic
+    //  of another; steps past the unit's last block unpack block 0 again and keep nothing)
+#pragma unroll
+    for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
+      if (2u * (uint32_t)i0 < nb_here) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; i++) {
+          uint32_t cs[4], blk_l;
+          bool live;
+          unpack4(i, cs, blk_l, live);
+          const uint32_t sc = half_incl_scan(cs[3]);
+          if ((lane & 31) == 31 && live) s_tot[blk_l] = sc;
+        }
+      }
+    }
+    __syncthreads();
+    if ((uint32_t)lane < nb_here && b0 + (uint32_t)lane + 1u < n_blocks)   // (the last block's sum is nobody's start)
+      s = (T)s_tot[lane] + (T)128 * DeltaTraits<T>::zigzag(E.min_delta);
+  } else {
+    for (uint32_t bs = 0; bs < nb_here;) {
+      if ((uint32_t)lane >= bs && (uint32_t)lane < be && b0 + (uint32_t)lane + 1u < n_blocks)
+        s = delta_block_sum<T>(win, E.data_off - win_a0, E.widths) + (T)128 * DeltaTraits<T>::zigzag(E.min_delta);
+      bs = be;
+      if (bs < nb_here) be = stage(bs);
+    }
+  }
+  const T incl = wave_incl_scan(s, lane);
+  const T total = bcast_lane(incl, 63);
+  if (lane == 0) {
+    publish_word(&w.gsum[2 * u], (uint32_t)total);
+    if (sizeof(T) == 8) publish_word(&w.gsum[2 * u + 1], (uint32_t)((uint64_t)total >> 32));
+  }
+  if (nb_here == 0u) return;
+  // the units before this one in the page: they started no later than this one and publish before they wait
+  T before = 0;
+  bool late = false;
+  for (uint32_t j0 = 0; j0 < g; j0 += 64u) {
+    const uint32_t j = j0 + (uint32_t)lane;
+    T v = 0;
+    if (j < g) {
+      const uint64_t *slot = &w.gsum[2 * (u - (int64_t)g + (int64_t)j)];
+      uint64_t a = 0, b = 0;
+      uint32_t spins = 0;
+      while (((a >> 32) == 0 || (b >> 32) == 0) && ++spins < kSpinLimit) {
+        if (spins > 1u) __builtin_amdgcn_s_sleep(2);
+        poll_raw<sizeof(T) == 8>(slot, &a, &b);
+      }
+      late = late || (a >> 32) == 0 || (b >> 32) == 0;
+      v = (T)((b << 32) | (uint32_t)a);
+    }
+    before += bcast_lane(wave_incl_scan(v, lane), 63);
+  }
+  if (__ballot(late) != 0ull) {
+    // a total never came (the units of a page did not start in order): the page is decoded again by the
+    // wavefront-per-page kernel that runs after this one
+    if (lane == 0) c.state[p].delta_fast = 2;
+    return;
+  }
+  if ((uint32_t)lane < kUnitBlocks) s_prev[lane] = (uint64_t)(T)(first + before + (T)(incl - s));
+  __syncthreads();
+
+  // ---- values ----
+  if (quick) {
+#pragma unroll
+    for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
+      if (2u * (uint32_t)i0 >= nb_here) break;
+#pragma unroll
+      for (int i = i0; i < i0 + 4; i++) {
+        uint32_t e4[4], blk_l;
+        bool live;
+        unpack4(i, e4, blk_l, live);
+        const uint32_t ex = half_incl_scan(e4[3]) - e4[3];
+        e4[0] += ex; e4[1] += ex; e4[2] += ex; e4[3] += ex;
+        const uint32_t ei = live ? blk_l : 0u;
+        const T prev = (T)s_prev[ei];
+        const T md = DeltaTraits<T>::zigzag(s_ent[ei].min_delta);
+        const uint32_t l4 = (uint32_t)(lane & 31) * 4u;
+        const T a1 = prev + md * (T)(l4 + 1u), a2 = a1 + md, a3 = a2 + md, a4 = a3 + md;
+        const T v0 = a1 + (T)e4[0], v1 = a2 + (T)e4[1], v2 = a3 + (T)e4[2], v3 = a4 + (T)e4[3];
+        const uint64_t idx = 1ull + (uint64_t)(b0 + blk_l) * 128u + l4;
+        if (sizeof(T) == 8 && __ballot(live && idx + 3 < (uint64_t)cnt) == ~0ull) {
+          // 64-bit values: a lane's 32 bytes go through LDS so that each store instruction writes 1 KiB without gaps
+          // (lane-major in LDS = value order in memory, the two blocks of a step being neighbours)
+          s_stage[2 * lane] = make_uint4((uint32_t)v0, (uint32_t)((uint64_t)v0 >> 32), (uint32_t)v1, (uint32_t)((uint64_t)v1 >> 32));
+          s_stage[2 * lane + 1] = make_uint4((uint32_t)v2, (uint32_t)((uint64_t)v2 >> 32), (uint32_t)v3, (uint32_t)((uint64_t)v3 >> 32));
+          const uint4 qa = s_stage[lane], qb = s_stage[64 + lane];
+          struct Q { uint32_t a, b, c, d; } __attribute__((packed));
+          uint8_t *region = reinterpret_cast<uint8_t *>(out + 1ull + (uint64_t)(b0 + 2u * (uint32_t)i) * 128u);
+          *reinterpret_cast<Q *>(region + 16 * lane) = Q{qa.x, qa.y, qa.z, qa.w};
+          *reinterpret_cast<Q *>(region + 1024 + 16 * lane) = Q{qb.x, qb.y, qb.z, qb.w};
+        } else if (live) {
+          if (idx + 3 < (uint64_t)cnt) {
+            if (sizeof(T) == 8) {
+              struct Q { uint64_t a, b; } __attribute__((packed));
+              *reinterpret_cast<Q *>(out + idx) = Q{(uint64_t)v0, (uint64_t)v1};
+              *reinterpret_cast<Q *>(out + idx + 2) = Q{(uint64_t)v2, (uint64_t)v3};
+            } else {
+              struct Q { uint32_t a, b, c, d; } __attribute__((packed));
+              *reinterpret_cast<Q *>(out + idx) = Q{(uint32_t)v0, (uint32_t)v1, (uint32_t)v2, (uint32_t)v3};
+            }
+          } else {
+            if (idx < (uint64_t)cnt) out[idx] = v0;
+            if (idx + 1 < (uint64_t)cnt) out[idx + 1] = v1;
+            if (idx + 2 < (uint64_t)cnt) out[idx + 2] = v2;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // anything else: widths up to 64, or more bytes than the window holds
+  if (!one_window) be = stage(0u);
+  for (uint32_t bs = 0; bs < nb_here;) {
+#pragma unroll 1
+    for (uint32_t i = bs; i < be; i += 2u) {
+      const uint32_t blk_l = i + (uint32_t)half;
+      const bool live = blk_l < be;
+      const DeltaBlock e = s_ent[live ? blk_l : i];
+      const T prev = (T)s_prev[live ? blk_l : i];
+      const uint32_t wm = (e.widths >> (8 * m)) & 0xFFu;
+      const uint32_t pre = m ? ((e.widths * 0x01010101u) >> (8 * (m - 1))) & 0xFFu : 0u;
+      const uint32_t bit0 = 32u * pre + 4u * (uint32_t)k * wm;
+      const uint32_t r = e.data_off - win_a0 + (bit0 >> 3);
+      const uint32_t shift = (r & 3u) * 8u + (bit0 & 7u);
+      const uint32_t *q = win + (r >> 2);
+      const uint64_t mask = wm >= 64u ? ~0ull : ((1ull << wm) - 1ull);
+      const T md = DeltaTraits<T>::zigzag(e.min_delta);
+      T t[4];
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        // every value from the three dwords that hold it
+        const uint32_t bit = shift + (uint32_t)v * wm;
+        const uint32_t *wp = q + (bit >> 5);
+        const uint32_t sh = bit & 31u;
+        const uint64_t a0 = wp[0], a1 = wp[1], a2 = wp[2];
+        uint64_t v64 = (a0 | (a1 << 32)) >> sh;
+        if (sh) v64 |= a2 << (64u - sh);
+        t[v] = (T)(wm ? (v64 & mask) : 0ull);
+      }
+      const T p0 = t[0] + md, p1 = p0 + t[1] + md, p2 = p1 + t[2] + md, p3 = p2 + t[3] + md;
+      const T base = prev + (T)(half_incl_scan(p3) - p3);
+      if (live) {
+        const uint64_t idx = 1ull + (uint64_t)(b0 + blk_l) * 128u + (uint32_t)(lane & 31) * 4u;
+        const T v0 = base + p0, v1 = base + p1, v2 = base + p2, v3 = base + p3;
+        if (idx + 3 < (uint64_t)cnt) {
+          if (sizeof(T) == 8) {
+            struct Q { uint64_t a, b; } __attribute__((packed));
+            *reinterpret_cast<Q *>(out + idx) = Q{(uint64_t)v0, (uint64_t)v1};
+            *reinterpret_cast<Q *>(out + idx + 2) = Q{(uint64_t)v2, (uint64_t)v3};
+          } else {
+            struct Q { uint32_t a, b, c, d; } __attribute__((packed));
+            *reinterpret_cast<Q *>(out + idx) = Q{(uint32_t)v0, (uint32_t)v1, (uint32_t)v2, (uint32_t)v3};
+          }
+        } else {
+          if (idx < (uint64_t)cnt) out[idx] = v0;
+          if (idx + 1 < (uint64_t)cnt) out[idx + 1] = v1;
+          if (idx + 2 < (uint64_t)cnt) out[idx + 2] = v2;
+        }
+      }
+    }
+    bs = be;
+    if (bs < nb_here) be = stage(bs);
+  }
+}
+
+size_t delta_work_bytes(int64_t slots, int nd) {
+  const size_t nb = (size_t)slots / 128 + 3 * (size_t)nd + 8, nu = (size_t)slots / 4096 + (size_t)nd + 8;
+  return 16 * nb + (16 + sizeof(DeltaUnit)) * nu + 128;
+}
+
+hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
+                               hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
+  if (work) {
+    const size_t nb = (size_t)slots / 128 + 3 * (size_t)c.nd + 8, nu = (size_t)slots / 4096 + (size_t)c.nd + 8;
+    DeltaWork w;
+    w.blocks = static_cast<DeltaBlock *>(work);
+    w.gsum = reinterpret_cast<uint64_t *>(w.blocks + nb);
+    w.units = reinterpret_cast<DeltaUnit *>((reinterpret_cast<uintptr_t>(w.gsum + 2 * nu) + 63) & ~(uintptr_t)63);
+    w.n_units = (int64_t)((size_t)slots / 4096 + (size_t)c.nd);
+    hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
+    const dim3 grid((unsigned)w.n_units);
+    if (elem_size == 4) hipLaunchKernelGGL(k_delta_units<uint32_t>, grid, dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
+    else hipLaunchKernelGGL(k_delta_units<uint64_t>, grid, dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
+  }
   if (elem_size == 4)
     hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel);
   else

@@ -217,8 +217,39 @@ template <int DMODE, class T>
 __device__ __forceinline__ T dict_lookup(const ExpandArgs &a, const uint8_t *s_dict, uint32_t idx) {
   if (DMODE == 0) return reinterpret_cast<const T *>(a.dict)[idx];
   if (DMODE == 1) return reinterpret_cast<const T *>(s_dict)[idx];
-  if (idx < (uint32_t)a.dict_lds_n) return reinterpret_cast<const T *>(s_dict)[idx];
-  return reinterpret_cast<const T *>(a.dict)[idx];
+  typedef const __attribute__((address_space(3))) T *LdsPtr;
+  typedef const __attribute__((address_space(1))) T *GlobalPtr;
+  const bool in = idx < (uint32_t)a.dict_lds_n;
+  T v = ((LdsPtr)s_dict)[in ? idx : 0u];
+  if (!in) v = ((GlobalPtr)a.dict)[idx];
+  return v;
+}
+
+// The eight lookups of an item.  With part of the dictionary in LDS (DMODE 2) every lane reads LDS for all eight
+// (index 0 where the entry is not there) and only the lanes beyond the LDS part load from global memory, into
+// registers of their own: the global loads of an item are all in flight before the first result is needed, and
+// none of them waits for an LDS read.  (One access through a pointer picked per lane would be a flat load, which
+// ties up both memory paths.)
+template <int DMODE, class T>
+__device__ __forceinline__ void dict_lookup8(const ExpandArgs &a, const uint8_t *s_dict, const uint32_t x[8], T y[8]) {
+  if (DMODE != 2) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, T>(a, s_dict, x[j]);
+    return;
+  }
+  typedef const __attribute__((address_space(3))) T *LdsPtr;
+  typedef const __attribute__((address_space(1))) T *GlobalPtr;
+  T yg[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    yg[j] = 0;
+    if (x[j] >= (uint32_t)a.dict_lds_n) yg[j] = ((GlobalPtr)a.dict)[x[j]];
+  }
+  T yl[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) yl[j] = ((LdsPtr)s_dict)[x[j] < (uint32_t)a.dict_lds_n ? x[j] : 0u];
+#pragma unroll
+  for (int j = 0; j < 8; j++) y[j] = x[j] < (uint32_t)a.dict_lds_n ? yl[j] : yg[j];
 }
 
 // The items of one staged tile.  GT threads; a wave takes 64 consecutive items per step.  The run holding an
@@ -294,13 +325,11 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       }
       if (MODE == 4) {
         uint32_t y[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint32_t>(a, s_dict, x[j]);
+        dict_lookup8<DMODE, uint32_t>(a, s_dict, x, y);
         store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
       } else {
         uint64_t y[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) y[j] = dict_lookup<DMODE, uint64_t>(a, s_dict, x[j]);
+        dict_lookup8<DMODE, uint64_t>(a, s_dict, x, y);
         store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
       }
     } else {

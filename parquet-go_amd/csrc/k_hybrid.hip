@@ -46,6 +46,7 @@ __global__ void k_page_setup(ChunkCtx c) {
   PageState ps;
   ps.status = 0; ps.n_nulls = 0; ps.n_rows = 0; ps.cnt = 0;
   ps.dense_base = 0; ps.byte_base = 0; ps.byte_len = 0; ps.val_off = 0; ps.val_len = 0; ps.aux0 = 0; ps.aux1 = 0;
+  ps.delta_fast = 0; ps.spare = 0;
   if (pi.data_idx < 0) {
     if (pi.page_type != PQD_DICTIONARY_PAGE) ps.status = PQD_ERR_UNSUPPORTED_PAGE_TYPE;
     c.state[p] = ps;
@@ -265,51 +266,80 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
         // one run at a time; the loop bound drops to 0 when the 64 runs of a flush say the stream is dense
         uint32_t hot_lim = (dense || jumpy) ? 0u : lim;
         bool long_header = false;
+        // Two phases per batch of up to 64 runs.  The chain itself - header at q, so the next header is at q + its
+        // length + the run's bytes - is all that has to happen one run after the other, so the serial phase does
+        // nothing else: it notes the positions (and keeps count of the values, to stop at the run that completes
+        // the count).  What a run is and where its values and items start is then worked out for all noted runs at
+        // once, one run per lane, with wave prefix sums.
         while (q < hot_lim && o32 < ucnt) {
-          const uint32_t run_q = q;
-          const uint32_t di = (q - wq) >> 2;
-          const uint32_t sh = (q & 3u) * 8u;
-          const uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
-          const uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
-          const uint32_t d2 = __builtin_amdgcn_readfirstlane(win[di + 2]);
-          const uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
-          const uint32_t x1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
-          const uint32_t two = (x0 >> 7) & 1u;
-          if (__builtin_expect((x0 & 0x8080u) == 0x8080u, 0)) { long_header = true; break; }  // header of 3 or more bytes
-          const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
-          const uint32_t hlen = 1u + two;
-          const uint32_t isbp = header & 1u;
-          const uint32_t cg = header >> 1;
-          const uint32_t nv = cg << (isbp * 3u);
-          const uint32_t nbytes = ((cg * (uint32_t)w) & (0u - isbp)) | (nb_rle & (isbp - 1u));
-          const uint32_t val = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * hlen)) & rle_mask;
-          const uint32_t bpm = 0u - isbp;  // all ones for a bit-packed run
-          const uint32_t e_y = ((q + hlen - a) & bpm) | (val & ~bpm);
-          const uint32_t e_x = (isbp << 31) | o32;
-          const uint32_t nq = q + hlen + nbytes;
-          q = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
-          if (__builtin_expect(nv == 0, 0)) continue;
-          const uint32_t endv = o32 + nv;
-          const uint32_t endc = endv < ucnt ? endv : ucnt;
-          const uint32_t kt = (o32 + kTile - 1) & ~(uint32_t)(kTile - 1);
-          if (__builtin_expect(kt < endc, 0))
-            for (uint32_t k = kt / kTile + lane; k * (uint32_t)kTile < endc; k += 64)
-              tile_run[k] = make_int2(nr, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(k * (uint32_t)kTile - o32) * (uint32_t)w) >> 3) : run_q - a));
-          if (lane == (nr & 63)) { ex = e_x; ey = e_y; ez = items; }
-          nr++;
-          items += (nv + 7u) >> 3;
-          if (__builtin_expect((nr & 63) == 0, 0)) {
-            runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
-            // how many of these 64 runs were RLE runs of fewer than 64 values (a one-byte header)?
-            const uint32_t nxt = (uint32_t)__shfl_down((int)(ex & 0x7FFFFFFFu), 1);
-            const uint32_t nvl = (lane == 63 ? endv : nxt) - (ex & 0x7FFFFFFFu);
-            dense = __builtin_popcountll(__ballot((ex >> 31) == 0u && nvl < 64u)) >= 48;
-            if (kJump) { jumpy = !dense && q - flush_q < 64u * kJumpRunBytes; flush_q = q; }
-            if (dense || jumpy) hot_lim = 0u;
+          const int slot0 = nr & 63;                 // pending entries sit in lanes [0, slot0)
+          const int cap = 64 - slot0;
+          int n = 0;
+          uint32_t qq = q, oo = o32;
+          uint32_t posv = 0;                          // lane slot0 + k: position of the k-th run of the batch
+          while (n < cap && qq < hot_lim && oo < ucnt) {
+            const uint32_t di = (qq - wq) >> 2;
+            const uint32_t sh = (qq & 3u) * 8u;
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(win[di]);
+            const uint32_t d1 = __builtin_amdgcn_readfirstlane(win[di + 1]);
+            const uint32_t x0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+            if (__builtin_expect((x0 & 0x8080u) == 0x8080u, 0)) { long_header = true; break; }  // header of 3 or more bytes
+            const uint32_t two = (x0 >> 7) & 1u;
+            const uint32_t header = (x0 & 0x7Fu) | (two ? ((x0 >> 1) & 0x3F80u) : 0u);
+            const uint32_t isbp = header & 1u;
+            const uint32_t cg = header >> 1;
+            const uint32_t nbytes = isbp ? cg * (uint32_t)w : nb_rle;
+            const uint32_t nq = qq + 1u + two + nbytes;
+            if (cg != 0u) {                           // (an empty run is stepped over)
+              if (lane == slot0 + n) posv = qq;
+              n++;
+              oo += cg << (isbp * 3u);
+            }
+            qq = nq < qend ? nq : qend;  // only a bit-packed payload can reach past the end: it is zero filled
           }
-          emit_end = endv;
-          emit_q = q;
-          o32 = endv;
+          q = qq;
+          if (n > 0) {
+            const int i = lane - slot0;
+            const bool in = i >= 0 && i < n;
+            const uint32_t qi = in ? posv : wq;   // (idle lanes read the start of the window)
+            const uint32_t dj = (qi - wq) >> 2, sj = (qi & 3u) * 8u;
+            const uint32_t e0 = win[dj], e1 = win[dj + 1], e2 = win[dj + 2];
+            const uint32_t y0 = __builtin_amdgcn_alignbit(e1, e0, sj), y1 = __builtin_amdgcn_alignbit(e2, e1, sj);
+            const uint32_t two = (y0 >> 7) & 1u;
+            const uint32_t header = (y0 & 0x7Fu) | (two ? ((y0 >> 1) & 0x3F80u) : 0u);
+            const uint32_t hlen = 1u + two, isbp = header & 1u, cg = header >> 1;
+            const uint32_t adv = hlen + (isbp ? cg * (uint32_t)w : nb_rle);
+            const uint32_t val = (uint32_t)((((uint64_t)y1 << 32) | y0) >> (8u * hlen)) & rle_mask;
+            const uint32_t e_y = isbp ? qi + hlen - a : val;
+            const uint32_t nvi = in ? cg << (isbp * 3u) : 0u;
+            const uint32_t incl_v = wave_incl_sum32(nvi);
+            const uint32_t iti = in ? (nvi + 7u) >> 3 : 0u;
+            const uint32_t incl_i = wave_incl_sum32(iti);
+            if (in) {
+              const uint32_t start = o32 + incl_v - nvi;
+              ex = (isbp << 31) | start; ey = e_y; ez = items + incl_i - iti;
+              const uint32_t endv = start + nvi, endc = endv < ucnt ? endv : ucnt;
+              for (uint32_t kt = (start + kTile - 1) / kTile; kt * (uint32_t)kTile < endc; kt++)
+                tile_run[kt] = make_int2(nr + i, (int)(isbp ? e_y + (uint32_t)(((uint64_t)(kt * (uint32_t)kTile - start) * (uint32_t)w) >> 3) : qi - a));
+            }
+            const int last = slot0 + n - 1;
+            o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, last);
+            items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, last);
+            const uint32_t after = (uint32_t)__builtin_amdgcn_readlane((int)(qi + adv), last);
+            nr += n;
+            emit_end = o32;
+            emit_q = after < qend ? after : qend;
+            if ((nr & 63) == 0) {
+              runs[nr - 64 + lane] = RunEntry{ex, ey, ez, 0u};
+              // how many of these 64 runs were RLE runs of fewer than 64 values (a one-byte header)?
+              const uint32_t nxt = (uint32_t)__shfl_down((int)(ex & 0x7FFFFFFFu), 1);
+              const uint32_t nvl = (lane == 63 ? o32 : nxt) - (ex & 0x7FFFFFFFu);
+              dense = __builtin_popcountll(__ballot((ex >> 31) == 0u && nvl < 64u)) >= 48;
+              if (kJump) { jumpy = !dense && q - flush_q < 64u * kJumpRunBytes; flush_q = q; }
+              if (dense || jumpy) hot_lim = 0u;
+            }
+          }
+          if (long_header) break;
         }
         if (long_header || !(dense || jumpy)) break;
         if (kJump && !dense) {

@@ -128,6 +128,7 @@ const Defaults &defaults() {
     if (std::getenv("PQD_NO_PLAIN_SCATTER")) x.opt[PQD_OPT_PLAIN_SCATTER] = 0;
     if (const char *e = std::getenv("PQD_SPLIT")) x.opt[PQD_OPT_SPLIT] = e[0] == '1';
     if (const char *e = std::getenv("PQD_POISON")) x.opt[PQD_OPT_POISON] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] == '1';
     const char *e = std::getenv("PQD_HEAVY_LANES");
     const int v = e ? std::atoi(e) : 0;
     x.heavy_lanes = v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
@@ -149,7 +150,7 @@ struct pqd_handle {
 
   DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
-  DevBuf row_starts, dba_flags;
+  DevBuf row_starts, dba_flags, delta_blocks;
   int64_t bytes_len = 0;
   HostBuf stage_in[2], stage_out, stage_meta, host_small;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};   // the copy out of stage_in[k] has been done
@@ -181,8 +182,9 @@ struct pqd_handle {
   std::vector<KernelEvent> events;   // pool
   size_t n_events = 0;               // used by the last call
 
-  DevBuf *all_bufs_[22] = {&in, &meta, &runs, &tile_run, &tile_desc, &dict, &values, &dense, &def, &rep, &offsets, &bytes,
-                           &scratch, &small, &pairs, &lens64, &prefix64, &parent, &doff, &dict_pairs, &row_starts, &dba_flags};
+  DevBuf *all_bufs_[23] = {&in, &meta, &runs, &tile_run, &tile_desc, &dict, &values, &dense, &def, &rep, &offsets, &bytes,
+                           &scratch, &small, &pairs, &lens64, &prefix64, &parent, &doff, &dict_pairs, &row_starts, &dba_flags,
+                           &delta_blocks};
 };
 
 namespace {
@@ -454,6 +456,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     // and DELTA_BYTE_ARRAY pages may expand beyond that and are then copied again by pqd_wait
     if ((rc = h->bytes.ensure((size_t)all_bytes + 64))) return rc;
   }
+  if (!levels_only && (any_delta || any_dlba || any_dba) &&
+      (rc = h->delta_blocks.ensure(delta_work_bytes(slots, nd)))) return rc;
   if (col->max_def > 0 && (rc = h->def.ensure(4 * (size_t)slots + 64))) return rc;
   if (col->max_rep > 0 && (rc = h->rep.ensure(4 * (size_t)slots + 64))) return rc;
   if (!levels_only) {
@@ -517,6 +521,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   int64_t *d_totals = static_cast<int64_t *>(h->small.p);
 
   uint8_t *dense_out = static_cast<uint8_t *>(nullable ? h->dense.p : h->values.p);
+  void *dtab = h->opt[PQD_OPT_DELTA_BLOCKS] == 0 ? nullptr : h->delta_blocks.p;
 
   // LDS reserved per tile for packed bytes.  Levels: the width is known here.  Dictionary indices: the width is
   // inside the page, so size it from the densest page's bytes per value (a tile that needs more still decodes,
@@ -627,13 +632,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
       HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, h->stream)); }
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, h->stream)); }
+      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
       { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
     }
@@ -674,7 +679,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     }
     if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-    if (any_delta) { Prof pf(h, "k_delta_decode"); HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, h->stream)); }
+    if (any_delta) { Prof pf(h, "k_delta_decode"); HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, h->stream)); }
     if (nullable && slots > 0) {
       Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
       if (plain_scatter)

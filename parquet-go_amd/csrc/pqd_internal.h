@@ -41,6 +41,34 @@ struct PageState {
   int64_t val_len;
   int64_t aux0;        // DELTA_LENGTH/DELTA_BYTE_ARRAY: chunk offset of the byte payload
   int64_t aux1;
+  int32_t delta_fast;  // the page's current delta stream has a block table: decoded block-parallel
+  int32_t spare;
+};
+
+// One 128-value block of a DELTA_BINARY_PACKED stream whose headers have been walked (k_delta_blocks): where its
+// first miniblock starts (bytes from the start of the stream), the four miniblock widths (0 for a miniblock the
+// stream does not hold) and the minimum delta as the varint holds it (zigzag still applied).
+struct __attribute__((aligned(16))) DeltaBlock {
+  uint32_t data_off;
+  uint32_t widths;
+  uint64_t min_delta;
+};
+
+// One unit of 64 consecutive blocks of such a stream (k_delta_units): all a wavefront needs to know to start on it,
+// in one 64-byte record.  page < 0: the unit holds nothing.  win_start / win_end: the bytes of its blocks, relative to
+// the start of the stream.
+struct __attribute__((aligned(64))) DeltaUnit {
+  int32_t page;
+  uint32_t g;          // index of the unit in its page
+  uint32_t n_blocks;   // blocks of the whole page
+  uint32_t win_start;
+  uint32_t win_end;
+  uint32_t spare;
+  int64_t tbase;       // index of the page's first DeltaBlock
+  int64_t src_off;     // chunk offset of the stream
+  int64_t out_base;    // index of the page's first value in the output
+  int64_t cnt;         // values the page wants
+  uint64_t first_raw;  // the stream's first value as its varint holds it
 };
 
 // One RLE/bit-packed hybrid stream (repetition levels, definition levels or dictionary indices of one page).

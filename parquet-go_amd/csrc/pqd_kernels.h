@@ -56,7 +56,10 @@ hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, ui
 // ---- k_delta.hip ----
 // one wavefront per page whose value encoding is `encoding`; elem_size 4 or 8; src_sel 1 continues at the end of
 // the page's previous delta stream
-hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel,
+// work: delta_work_bytes(slots, pages) bytes (slots = the level slots of the call's data pages), or nullptr to
+// decode every page with the wavefront-per-page kernel
+size_t delta_work_bytes(int64_t slots, int nd);
+hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
                                hipStream_t stream);
 
 // ---- k_bytes.hip ----

@@ -23,7 +23,7 @@ def dec(shared_dec):
     # one handle for the module (its work buffers are reused from test to test, as a reader reuses them from chunk
     # to chunk); kernel-variant choices a test pins are handed back to the library afterwards
     yield shared_dec
-    for opt in range(6):
+    for opt in range(7):
         shared_dec.set_option(opt, -1)
 
 
@@ -367,6 +367,31 @@ def test_delta_binary_packed(dec, oracle, dtype, ptype):
             cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, n, enc)
     chunk, pages = cb.finish()
     check_same(dec, oracle, chunk, pages, ptype)
+
+
+@pytest.mark.parametrize("blocks", [1, 0])
+@pytest.mark.parametrize("n_pages,page_values", [(3, 70001), (600, 1500), (2100, 700)])
+def test_delta_block_parallel_and_wave_per_page_agree_with_the_oracle(dec, oracle, n_pages, page_values, blocks):
+    # standard 128 / 4 streams go through a table of block starts and are decoded by one, four or sixteen wavefronts
+    # per page, depending on how many pages there are; widths below and above 24 bits, width 0, 63-bit deltas that
+    # wrap around, INT32; last blocks that are partial; and the same pages with the table switched off
+    from gen import pqgen
+    dec.set_option(6, blocks)                # PQD_OPT_DELTA_BLOCKS
+    for w, esz, ptype in ((12, 8, pg.INT64), (0, 8, pg.INT64), (24, 8, pg.INT64), (25, 8, pg.INT64), (40, 8, pg.INT64), (63, 8, pg.INT64),
+                          (12, 4, pg.INT32), (31, 4, pg.INT32)):
+        if n_pages > 100 and w in (0, 24, 40):
+            continue
+        chunk, pages = pqgen.delta_chunk(0xD0 + w, n_pages * page_values - 5, w, page_values, esz, 1_700_000_000_000_000 if esz == 8 else 7)
+        g = dec.decode(chunk, pages, ptype)
+        o = oracle.read_chunk(chunk, pages, ptype)
+        assert g.status == o.status == 0, (w, esz, g.status, g.bad_page)
+        assert np.array_equal(g.values, o.values), (w, esz)
+    # a stream cut inside a block, a block header cut short: the general path's cases
+    chunk, pages = pqgen.delta_chunk(0xD9, 3 * 5000, 12, 5000)
+    for cut in (7, 300, 4001):
+        pp = pages.copy()
+        pp["length"][1] = cut
+        check_same(dec, oracle, chunk, pp, pg.INT64)
 
 
 def test_delta_reference_writer_and_other_geometries(dec, oracle):
