@@ -471,7 +471,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // earlier call (or a failed page) left behind shows up as a difference from the reference or as a refused index
   if (h->opt[PQD_OPT_POISON] > 0) {
     for (DevBuf *b : h->all_bufs_)
-      if (b != &h->in && b->p && b->cap) HIP_TRY(hipMemsetAsync(b->p, 0xFF, b->cap, h->stream));
+      if (b != &h->in && b->p && b->cap) {
+        // (a buffer of the caller is recorded 64 bytes longer than it is - slack that no kernel writes - and must not be filled past its end)
+        const size_t n = b->fixed ? (b->cap > 64 ? b->cap - 64 : 0) : b->cap;
+        if (n) HIP_TRY(hipMemsetAsync(b->p, 0xFF, n, h->stream));
+      }
   }
 
   h->levels_only = levels_only;
