@@ -667,52 +667,60 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
 // bases, and the descriptor of the value section (dictionary pages: first byte is the index width, the rest is the
 // hybrid stream, layout/page.go:644-655).  Three steps, so that a chunk of tens of thousands of small pages (the
 // reference's writer cuts pages at 8 KiB) is not walked by a single workgroup: counts per page (one thread per
-// page), one workgroup scanning the counts, value streams per page.
+// page) summed per block of 256 pages, one workgroup scanning the block sums, then bases and value streams per page.
 // totals: [0] slots [1] values [2] nulls [3] rows
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pages_count(ChunkCtx c) {
+// block_sums: four totals (slots, values, nulls, rows) per block of 256 pages
+__global__ __launch_bounds__(256) void k_pages_count(ChunkCtx c, int64_t *__restrict__ block_sums) {
+  __shared__ int64_t s_part[4][4];
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= c.n_pages) return;
-  const PageIn pi = c.pages[p];
-  if (pi.data_idx < 0) return;
-  PageState *ps = &c.state[p];
-  // a failed level stream fails the page
-  int st = ps->status;
-  if (st == 0 && c.max_rep > 0) st = c.streams[pi.data_idx].status;
-  if (st == 0 && c.max_def > 0) st = c.streams[c.nd + pi.data_idx].status;
-  const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
-  const int64_t nulls = c.max_def > 0 ? ps->n_nulls : 0;
-  const int64_t rows = c.max_rep > 0 ? ps->n_rows : nv;
-  ps->status = st;
-  ps->n_nulls = (int32_t)nulls;
-  ps->n_rows = (int32_t)rows;
-  ps->cnt = st != 0 ? 0 : (int32_t)(nv - nulls);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t sum[4] = {0, 0, 0, 0};
+  if (p < c.n_pages) {
+    const PageIn pi = c.pages[p];
+    if (pi.data_idx >= 0) {
+      PageState *ps = &c.state[p];
+      // a failed level stream fails the page
+      int st = ps->status;
+      if (st == 0 && c.max_rep > 0) st = c.streams[pi.data_idx].status;
+      if (st == 0 && c.max_def > 0) st = c.streams[c.nd + pi.data_idx].status;
+      const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
+      const int64_t nulls = c.max_def > 0 ? ps->n_nulls : 0;
+      const int64_t rows = c.max_rep > 0 ? ps->n_rows : nv;
+      const int64_t cnt = st != 0 ? 0 : nv - nulls;
+      ps->status = st;
+      ps->n_nulls = (int32_t)nulls;
+      ps->n_rows = (int32_t)rows;
+      ps->cnt = (int32_t)cnt;
+      sum[0] = nv; sum[1] = cnt; sum[2] = nulls; sum[3] = rows;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    int64_t t = sum[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if (lane == 0) s_part[q][wave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) block_sums[4 * (int64_t)blockIdx.x + threadIdx.x] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
 }
 
-__global__ __launch_bounds__(1024) void k_pages_finalize(ChunkCtx c, int64_t *totals) {
-  constexpr int kPer = 16;                      // consecutive pages per thread and round: their loads overlap
+// One workgroup: the totals of the call, and in place of every block's value count the values in front of the block.
+__global__ __launch_bounds__(1024) void k_pages_finalize(int n_blocks, int64_t *__restrict__ block_sums, int64_t *__restrict__ totals) {
   __shared__ int64_t s_wave[16];
-  __shared__ unsigned long long s_tot[4];       // running totals: slots, values, nulls, rows
+  __shared__ unsigned long long s_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 4) s_tot[tid] = 0;
   __syncthreads();
-  for (int p0 = 0; p0 < c.n_pages; p0 += 1024 * kPer) {
-    const int64_t carry_cnt = (int64_t)s_tot[1];  // values of the pages before this round
-    int64_t cnt[kPer], sum[4] = {0, 0, 0, 0};
-    bool data[kPer];
+  for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+    const int64_t carry = (int64_t)s_tot[1];
+    const int b = b0 + tid;
+    int64_t sum[4] = {0, 0, 0, 0};
+    if (b < n_blocks) {
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-      const int p = p0 + tid * kPer + j;
-      cnt[j] = 0;
-      data[j] = p < c.n_pages && c.pages[p].data_idx >= 0;
-      if (data[j]) {
-        const int64_t nv = c.pages[p].num_values > 0 ? c.pages[p].num_values : 0;
-        const PageState *ps = &c.state[p];
-        cnt[j] = ps->cnt;
-        sum[0] += nv; sum[1] += cnt[j]; sum[2] += ps->n_nulls; sum[3] += ps->n_rows;
-      }
+      for (int q = 0; q < 4; q++) sum[q] = block_sums[4 * (int64_t)b + q];
     }
-    // exclusive scan of the threads' value counts: inside the wave by shuffles, across the 16 waves through LDS
     int64_t x = sum[1];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -723,29 +731,38 @@ __global__ __launch_bounds__(1024) void k_pages_finalize(ChunkCtx c, int64_t *to
       int64_t t = sum[q];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
-      if (lane == 0 && t != 0) atomicAdd(&s_tot[q], (unsigned long long)t);   // read again after the barrier that ends the round
+      if (lane == 0 && t != 0) atomicAdd(&s_tot[q], (unsigned long long)t);
     }
-    int64_t base = carry_cnt + x - sum[1];
+    int64_t base = carry + x - sum[1];
     for (int k = 0; k < wave; k++) base += s_wave[k];
-#pragma unroll
-    for (int j = 0; j < kPer; j++) {
-      if (data[j]) c.state[p0 + tid * kPer + j].dense_base = base;
-      base += cnt[j];
-    }
+    if (b < n_blocks) block_sums[4 * (int64_t)b + 1] = base;
     __syncthreads();   // s_wave and the read of s_tot[1] at the top of the next round
   }
   if (tid < 4) totals[tid] = (int64_t)s_tot[tid];
 }
 
-__global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c) {
+__global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c, const int64_t *__restrict__ block_sums) {
+  __shared__ int64_t s_wave[4];
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= c.n_pages) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool is_data = p < c.n_pages && c.pages[p].data_idx >= 0;
+  // the page's place among the values of the call: the values in front of its block of pages, and an exclusive
+  // scan of the counts inside the block
+  const int64_t my_cnt = is_data ? c.state[p].cnt : 0;
+  int64_t x = my_cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  int64_t dense_base = block_sums[4 * (int64_t)blockIdx.x + 1] + x - my_cnt;
+  for (int k = 0; k < wave; k++) dense_base += s_wave[k];
+  if (!is_data) return;
   const PageIn pi = c.pages[p];
-  if (pi.data_idx < 0) return;
   PageState *ps = &c.state[p];
+  ps->dense_base = dense_base;
   Stream *vs = &c.streams[2 * c.nd + pi.data_idx];
   const int64_t cnt = ps->cnt;
-  vs->out_base = ps->dense_base;
+  vs->out_base = dense_base;
   vs->cnt = 0;
   vs->status = ps->status;
   const bool dict_enc = pi.encoding == PQD_ENC_PLAIN_DICTIONARY || pi.encoding == PQD_ENC_RLE_DICTIONARY;
@@ -800,8 +817,20 @@ constexpr int kDirectMaxLen = 64 * 1024;
 template <typename T, bool kLevels>
 __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
                                                         int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
+  // One round takes 1024 runs, four consecutive runs per thread.  The bytes of the stream come into LDS in 16-byte
+  // pieces, 8 KiB at a time (a page of the reference's writer fits whole); every thread parses its runs and asks for
+  // their dictionary entries together; a scan of the counts gives the runs their places, and the values go out by
+  // position - four consecutive values per thread, the run that covers the first of them found by bisection over
+  // the places - so that the stores are as wide and as dense as the output allows.  Nothing is checked ahead of time:
+  // a header of another shape anywhere, or too few values, and the stream is left to the general path, which writes
+  // the same places again.
+  constexpr int kWin = 8192;
+  constexpr int kRound = 1024;
+  __shared__ uint4 s_in4[kWin / 16 + 1];
+  __shared__ uint32_t s_start[kRound + 1];
+  __shared__ T s_val[kRound];
   __shared__ uint32_t s_sum[4];
-  __shared__ int s_flag[4];
+  const uint32_t *s_in = reinterpret_cast<const uint32_t *>(s_in4);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int si = kLevels ? (int)blockIdx.x : 2 * c.nd + (int)blockIdx.x;
   const bool is_def = kLevels && si >= c.nd;
@@ -822,65 +851,141 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   const int n_runs = (int)((uint32_t)len / stride);
   const uint32_t vmask = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
   const uint8_t *src = c.in + sp->off;
-  // every header: one byte, RLE, not empty; and the values they announce
-  uint32_t total = 0;
-  int bad = 0;
-  for (int k = tid; k < n_runs; k += 256) {
-    const uint32_t hb = src[(uint32_t)k * stride];
-    bad |= (hb & 0x81u) != 0u || hb == 0u;
-    total += hb >> 1;
-  }
-  for (int o = 32; o > 0; o >>= 1) { total += __shfl_down(total, o); bad |= __shfl_down(bad, o); }
-  if (lane == 0) { s_sum[wv] = total; s_flag[wv] = bad; }
-  __syncthreads();
-  total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-  bad = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
-  if (bad || total < (uint32_t)cnt) return;
+  const uint8_t *in_end = c.in + c.in_len;
   T *out = kLevels ? reinterpret_cast<T *>(is_def ? def_out : rep_out) + sp->out_base : values_out + sp->out_base;
+  const uint32_t out_al = (uint32_t)((reinterpret_cast<uintptr_t>(out) / sizeof(T)) & 3u);   // elements past a 4-element boundary
   const uint32_t flag_val = is_def ? (uint32_t)c.max_def : 0u;
   uint32_t carry = 0;
-  int bad_index = 0, n_flag = 0;
-  for (int k0 = 0; k0 < n_runs && carry < (uint32_t)cnt; k0 += 256) {
-    const int k = k0 + tid;
-    uint32_t n = 0, val = 0;
-    if (k < n_runs) {
-      const uint8_t *r = src + (uint32_t)k * stride;
-      n = (uint32_t)r[0] >> 1;
-      val = ((uint32_t)r[1] | (nb > 1 ? (uint32_t)r[2] << 8 : 0u) | (nb > 2 ? (uint32_t)r[3] << 16 : 0u) | (nb > 3 ? (uint32_t)r[4] << 24 : 0u)) & vmask;
+  int bad = 0, bad_index = 0, n_flag = 0;
+  int win_first = 0, win_runs = 0;         // runs [win_first, win_first + win_runs) have their bytes in LDS
+  uint32_t win_al = 0;
+  for (int k0 = 0; k0 < n_runs; k0 += kRound) {
+    const int in_round = n_runs - k0 < kRound ? n_runs - k0 : kRound;
+    __syncthreads();                       // the previous round's readers of s_in, s_start and s_val are done
+    if (k0 + in_round > win_first + win_runs) {
+      // ---- the next window of bytes, from this round on ----
+      const uint8_t *r0 = src + (uint32_t)k0 * stride;
+      win_al = (uint32_t)(reinterpret_cast<uintptr_t>(r0) & 15u);
+      const int fit = (int)(((uint32_t)kWin - win_al) / stride);
+      win_first = k0;
+      win_runs = n_runs - k0 < fit ? n_runs - k0 : fit;      // (fit >= 1024: a round always fits)
+      const uint32_t need = win_al + (uint32_t)win_runs * stride;
+#pragma unroll
+      for (int j = 0; j < kWin / 16 / 256; j++) {
+        const int ci = tid + 256 * j;
+        if ((uint32_t)ci * 16u < need) {
+          const uint8_t *q = r0 - win_al + 16 * ci;
+          s_in4[ci] = q < in_end ? *reinterpret_cast<const uint4 *>(q) : make_uint4(0u, 0u, 0u, 0u);   // (its granule holds bytes of the buffer)
+        }
+      }
+      __syncthreads();
     }
-    uint32_t incl = n;
+    // ---- four runs per thread ----
+    uint32_t n[4], val[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int kr = 4 * tid + j;
+      n[j] = 0; val[j] = 0;
+      if (kr < in_round) {
+        const uint32_t bo = win_al + (uint32_t)(k0 - win_first + kr) * stride;
+        const uint64_t x = (((uint64_t)s_in[(bo >> 2) + 1] << 32) | s_in[bo >> 2]) >> (8u * (bo & 3u));
+        const uint32_t hb = (uint32_t)x & 0xFFu;
+        bad |= (hb & 0x81u) != 0u || hb == 0u;   // one byte, RLE, not empty
+        n[j] = hb >> 1;
+        val[j] = (uint32_t)(x >> 8) & vmask;
+      }
+      mine += n[j];
+    }
+    T v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (kLevels) {
+        v[j] = (T)val[j];
+      } else {
+        uint32_t idx = val[j];
+        if (n[j] > 0 && idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
+        v[j] = (n[j] > 0 && dict_n > 0) ? dict[idx] : T(0);
+      }
+    }
+    uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t y = __shfl_up(incl, o);
       if (lane >= o) incl += y;
     }
-    __syncthreads();  // the previous round's sums have been read
     if (lane == 63) s_sum[wv] = incl;
     __syncthreads();
-    uint32_t before = carry, round = 0;
+    uint32_t before = 0, round = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) { if (q < wv) before += s_sum[q]; round += s_sum[q]; }
-    const uint32_t start = before + incl - n;
-    if (n > 0 && start < (uint32_t)cnt) {
-      const uint32_t end = start + n < (uint32_t)cnt ? start + n : (uint32_t)cnt;
-      T v;
-      if (kLevels) {
-        v = (T)val;
-        if (is_def ? val != flag_val : val == flag_val) n_flag += (int)(end - start);
-      } else {
-        uint32_t idx = val;
-        if (idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
-        v = dict_n > 0 ? dict[idx] : T(0);
+    if (carry < (uint32_t)cnt) {
+      uint32_t start = before + incl - mine;           // place of the thread's first run inside the round
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (kLevels && n[j] > 0 && carry + start < (uint32_t)cnt) {
+          const uint32_t end = carry + start + n[j] < (uint32_t)cnt ? start + n[j] : (uint32_t)cnt - carry;
+          if (is_def ? val[j] != flag_val : val[j] == flag_val) n_flag += (int)(end - start);
+        }
+        s_start[4 * tid + j] = start;
+        s_val[4 * tid + j] = v[j];
+        start += n[j];
       }
-      for (uint32_t j = start; j < end; j++) out[j] = v;
+      __syncthreads();
+      // ---- the round's values, by position ----
+      const uint32_t limit = carry + round < (uint32_t)cnt ? round : (uint32_t)cnt - carry;   // values of the round that are wanted
+      const uint32_t shift = (out_al + carry) & 3u;       // the round's first value sits this far into a group of four
+      for (uint32_t g0 = 0; g0 * 4u < limit + shift; g0 += 256u) {
+        const uint32_t g = g0 + (uint32_t)tid;
+        const int64_t p0 = (int64_t)g * 4 - (int64_t)shift;            // position of the group's first element in the round
+        if (p0 < (int64_t)limit && p0 + 4 > 0) {
+          // the run that covers the first wanted position of the group
+          const uint32_t first = p0 < 0 ? 0u : (uint32_t)p0;
+          int lo = 0, hi = in_round - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_start[mid] <= first) lo = mid; else hi = mid - 1;
+          }
+          int k = lo;
+          T vv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int64_t pos = p0 + j;
+            vv[j] = T(0);
+            if (pos >= 0 && pos < (int64_t)limit) {
+              while (k + 1 < in_round && s_start[k + 1] <= (uint32_t)pos) k++;
+              vv[j] = s_val[k];
+            }
+          }
+          T *dst = out + (int64_t)carry + p0;
+          if (p0 >= 0 && p0 + 4 <= (int64_t)limit) {
+            if (sizeof(T) == 4) {
+              *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)vv[0], (uint32_t)vv[1], (uint32_t)vv[2], (uint32_t)vv[3]);
+            } else {
+              reinterpret_cast<uint4 *>(dst)[0] = make_uint4((uint32_t)vv[0], (uint32_t)((uint64_t)vv[0] >> 32), (uint32_t)vv[1], (uint32_t)((uint64_t)vv[1] >> 32));
+              reinterpret_cast<uint4 *>(dst)[1] = make_uint4((uint32_t)vv[2], (uint32_t)((uint64_t)vv[2] >> 32), (uint32_t)vv[3], (uint32_t)((uint64_t)vv[3] >> 32));
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (p0 + j >= 0 && p0 + j < (int64_t)limit) dst[j] = vv[j];
+          }
+        }
+      }
     }
     carry += round;
   }
+  // ---- the verdict ----
+  for (int o = 32; o > 0; o >>= 1) bad |= __shfl_down(bad, o);
+  __syncthreads();
+  if (lane == 0) s_sum[wv] = (uint32_t)bad;
+  __syncthreads();
+  bad = (int)(s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3]);
+  if (bad || carry < (uint32_t)cnt) return;     // (uniform) not this shape, or too few values: the general path
   if (kLevels) {
     for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
     if (lane == 0 && n_flag) atomicAdd(is_def ? &c.state[sp->page].n_nulls : &c.state[sp->page].n_rows, n_flag);
   }
   if (__syncthreads_or(bad_index)) { if (tid == 0) set_status(&c.state[sp->page].status, PQD_ERR_MALFORMED); }
-  if (tid == 0) { sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)total; }
+  if (tid == 0) { sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)carry; }
 }
 
 hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict_table, uint8_t *values_out, hipStream_t stream) {
@@ -965,10 +1070,11 @@ hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t st
   return hipGetLastError();
 }
 
-hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream) {
-  if (c.n_pages > 0) hipLaunchKernelGGL(k_pages_count, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c);
-  hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(1024), 0, stream, c, totals);
-  if (c.n_pages > 0) hipLaunchKernelGGL(k_pages_values, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c);
+hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, int64_t *block_sums, hipStream_t stream) {
+  const int n_blocks = (c.n_pages + 255) / 256;
+  if (n_blocks > 0) hipLaunchKernelGGL(k_pages_count, dim3(n_blocks), dim3(256), 0, stream, c, block_sums);
+  hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(1024), 0, stream, n_blocks, block_sums, totals);
+  if (n_blocks > 0) hipLaunchKernelGGL(k_pages_values, dim3(n_blocks), dim3(256), 0, stream, c, block_sums);
   return hipGetLastError();
 }
 

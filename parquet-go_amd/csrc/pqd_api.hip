@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <cstdio>
@@ -160,6 +161,8 @@ struct pqd_handle {
   // description of the last decode call
   std::vector<PageIn> h_pages;
   std::vector<int32_t> h_dict_pages;
+  std::vector<StreamSeed> h_seeds;
+  std::vector<int32_t> h_tp_levels, h_tp_dict, h_tp_plain;
   pqd_column_desc col{};
   int n_pages = 0, nd = 0;
   int64_t total_slots = 0;
@@ -305,6 +308,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     HIP_TRY(hipStreamSynchronize(h->stream));
     set_busy(h, false);
   }
+  static const bool host_timing = std::getenv("PQD_HOST_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_begin = tnow();
   h->have_result = false;
   h->plan = pqd_handle::BytesPlan{};
   const int esz = elem_size_of(*col);
@@ -369,27 +375,42 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       }
     }
   }
+  auto t_pages = tnow();
   if (slots > 0x7FFFFFFF0ll) return fail_arg("too many level slots in one call");
   const int n_dict = (int)h->h_dict_pages.size();
 
   // ---- meta block: pages | seeds | tile prefixes | tile -> stream maps | dictionary pages; then, device only,
   //      state | streams ----
   const size_t n_streams = (size_t)3 * nd;
-  std::vector<StreamSeed> h_seeds(n_streams);
-  std::vector<int32_t> tp_levels(2 * (size_t)nd + 1, 0), tp_dict((size_t)nd + 1, 0), tp_plain((size_t)nd + 1, 0);
+  // (the host arrays belong to the handle: allocating and clearing megabytes per call costs more than filling them)
+  std::vector<StreamSeed> &h_seeds = h->h_seeds;
+  std::vector<int32_t> &tp_levels = h->h_tp_levels, &tp_dict = h->h_tp_dict, &tp_plain = h->h_tp_plain;
+  h_seeds.resize(n_streams);
+  tp_levels.resize(2 * (size_t)nd + 1); tp_dict.resize((size_t)nd + 1); tp_plain.resize((size_t)nd + 1);
   int64_t run_total = 0, tile_total = 0;
   {
-    if (n_streams) std::memset(h_seeds.data(), 0, n_streams * sizeof(StreamSeed));
     int64_t t_lv = 0, t_dc = 0, t_pl = 0;
     for (int g = 0; g < 3; g++) {
+      const bool group_wanted = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) || (g == 2 && !levels_only);
+      if (!group_wanted) {
+        // a group no stream of which is decoded: empty run ranges, one (end) entry in the tile table each
+        StreamSeed *sg = h_seeds.data() + (size_t)g * nd;
+        for (int d = 0; d < nd; d++) {
+          sg[d].run_base = run_total; sg[d].run_cap = 0; sg[d].tile_base = (int32_t)(tile_total + d);
+          if (g < 2) tp_levels[(size_t)g * nd + d] = (int32_t)t_lv;
+          else { tp_dict[(size_t)d] = (int32_t)t_dc; tp_plain[(size_t)d] = (int32_t)t_pl; }
+        }
+        tile_total += nd;
+        if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
+        continue;
+      }
       for (int p = 0; p < n_pages; p++) {
         const PageIn &pi = h->h_pages[(size_t)p];
         if (pi.data_idx < 0) continue;
         const int d = pi.data_idx;
         StreamSeed &s = h_seeds[(size_t)g * nd + d];
         const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
-        const bool want = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) ||
-                          (g == 2 && !levels_only && (is_dict_enc(pi.encoding) || (pi.encoding == PQD_ENC_RLE && rle_typed && !is_bytes)));
+        const bool want = g < 2 || is_dict_enc(pi.encoding) || (pi.encoding == PQD_ENC_RLE && rle_typed && !is_bytes);
         const int64_t tiles = want ? (nv + kTile - 1) / kTile : 0;
         const int64_t rcap = want ? std::min<int64_t>(nv, pi.body_len) + 2 : 0;
         s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total;
@@ -412,6 +433,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     tp_dict[(size_t)nd] = (int32_t)t_dc;
     tp_plain[(size_t)nd] = (int32_t)t_pl;
   }
+  auto t_seeds = tnow();
   const size_t off_pages = 0;
   const size_t off_seeds = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
   const size_t off_tp_lv = align_up(off_seeds + sizeof(StreamSeed) * n_streams, 256);
@@ -423,7 +445,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   const size_t upload_bytes = align_up(off_dictp + 4 * (size_t)n_dict, 256);
   const size_t off_state = upload_bytes;
   const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
-  const size_t meta_bytes = align_up(off_streams + sizeof(Stream) * n_streams, 256);
+  const size_t off_pgsum = align_up(off_streams + sizeof(Stream) * n_streams, 256);
+  const size_t meta_bytes = align_up(off_pgsum + 32 * (((size_t)n_pages + 255) / 256 + 1), 256);
 
   // ---- workspaces and outputs (every allocation of the call happens here, before anything is enqueued) ----
   if (h->no_alloc) {
@@ -478,6 +501,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       }
   }
 
+  auto t_ensure = tnow();
   h->levels_only = levels_only;
   h->n_events = 0;
   h->col = *col;
@@ -501,7 +525,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     for (size_t i = 0; i + 1 < tp_dict.size(); i++)
       for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
   }
+  auto t_stage = tnow();
   HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
+  auto t_h2d = tnow();
 
   uint8_t *mb = static_cast<uint8_t *>(h->meta.p);
   ChunkCtx c;
@@ -611,7 +637,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
     }
   }
-  { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, h->stream)); }
+  { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, reinterpret_cast<int64_t *>(mb + off_pgsum), h->stream)); }
   if (levels_only) {
     // skip path (layout/page.go:433-559): levels, null and row counts; the value sections stay as they are
   } else if (is_bytes) {
@@ -701,6 +727,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   h->result.status = host_status;
   h->result.bad_page = host_bad;
   set_busy(h, true);
+  if (host_timing) {
+    auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+    auto t_end = tnow();
+    std::fprintf(stderr, "pqd host: pages %.1f us, seeds %.1f, ensure %.1f, staging %.1f, h2d call %.1f, launches %.1f (n_pages %d, upload %zu bytes)\n",
+                 us(t_begin, t_pages), us(t_pages, t_seeds), us(t_seeds, t_ensure), us(t_ensure, t_stage), us(t_stage, t_h2d), us(t_h2d, t_end), n_pages, upload_bytes);
+  }
   return PQD_OK;
 }
 

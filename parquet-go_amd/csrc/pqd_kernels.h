@@ -24,7 +24,8 @@ hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStrea
 hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
                                 int stage_bytes, int32_t *rep_out, int32_t *def_out, TileDesc *descs, int n_cu,
                                 hipStream_t stream);
-hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, hipStream_t stream);
+// block_sums: 32 bytes per 256 pages (device work space)
+hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, int64_t *block_sums, hipStream_t stream);
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream);
 // dictionary indices -> gathered values, for the tiles [tile_lo, tile_hi) (the data pages that share one dictionary;
 // `dict` points at its first entry; dict_n < 0: they have none and their indices pass through).  split_mode 0 / 1 pins the mid-size dictionary variant, -1 chooses by shared_gpu
