@@ -30,10 +30,11 @@ struct ExpandArgs {
   int32_t no_dict;             // the pages of this launch have no dictionary: their indices pass through unchecked
   int32_t dict_lds_n;          // entries [0, dict_lds_n) are staged in LDS
   int32_t dict_lds_bytes;      // LDS reserved for them (multiple of 16)
-  int32_t runs_cap;            // run-slice entries a group keeps in LDS (+ 3)
+  int32_t runs_cap;            // most run-slice entries a tile may keep in LDS (+ 3)
   int32_t mark_cap;            // items per tile the mark array holds
-  int32_t stage_bytes;         // LDS bytes for the packed bytes of one tile (multiple of 16)
-  int32_t group_bytes;         // LDS of one group: runs | segments | marks | packed bytes
+  int32_t pool_bytes;          // LDS a tile's run slice and packed bytes share (multiple of 16): a tile of many runs has
+                               // few packed bytes (an RLE run carries none) and a tile of many packed bytes few runs
+  int32_t group_bytes;         // LDS of one group: segments | marks | pool (run slice, then packed bytes)
   uint8_t *values_out;
   TileDesc *descs;             // n_tiles entries, written by k_tile_desc
 };
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
   const int b_hi = tk1.y + (int)w + 1;
   d.org = b_lo - (int)((reinterpret_cast<uintptr_t>(c.in + d.in_off) + (uintptr_t)(uint32_t)b_lo) & 15u);
   d.span = b_hi - d.org;
-  const bool in_lds = d.nr <= a.runs_cap + 2 && d.span + 8 <= a.stage_bytes && d.n_items <= a.mark_cap;
+  const bool in_lds = d.nr <= a.runs_cap + 2 && (d.nr + 1) * (int)sizeof(RunEntry) + ((d.span + 8 + 15) & ~15) <= a.pool_bytes && d.n_items <= a.mark_cap;
   // bit 3: the values are the unpacked numbers themselves (Encoding_RLE data pages, layout/page.go:657-667)
   // (also set for dictionary-encoded pages that have no dictionary page in front of them: the call fails for them
   //  with its own code, and the stream's own errors, which come first in the reference, are still found)
@@ -275,81 +276,158 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
       r = r > m ? r : m;
     }
     r = wave_incl_max(r);
-    if (!active) continue;
-    const RunEntry e = s_runs[r];
-    const int next_rel = (int)(s_runs[r + 1].x & 0x7FFFFFFFu) - d.t0;
-    const uint32_t kk = d.item_lo + (uint32_t)q - e.z;
-    const int vrel = (int)(e.x & 0x7FFFFFFFu) - d.t0 + (int)(kk << 3);  // tile-relative position of the item's value 0
-    const int j0 = vrel < 0 ? -vrel : 0;
-    const int lim = next_rel < tn ? next_rel : tn;
-    const int j1 = lim - vrel < 8 ? lim - vrel : 8;
-    uint32_t x[8];
-    const bool bp = e.x >> 31;
-    if (bp) {
-      const uint32_t rel = e.y - (uint32_t)d.org + kk * (uint32_t)W;
-      if (rel + (uint32_t)W + 8u <= staged) {
-        unpack8<W>(s_stage, rel, x);
+    uint32_t out4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j0 = 0, j1 = 0;
+    int64_t oidx = 0;
+    if (active) {
+      const RunEntry e = s_runs[r];
+      const int next_rel = (int)(s_runs[r + 1].x & 0x7FFFFFFFu) - d.t0;
+      const uint32_t kk = d.item_lo + (uint32_t)q - e.z;
+      const int vrel = (int)(e.x & 0x7FFFFFFFu) - d.t0 + (int)(kk << 3);  // tile-relative position of the item's value 0
+      j0 = vrel < 0 ? -vrel : 0;
+      const int lim = next_rel < tn ? next_rel : tn;
+      j1 = lim - vrel < 8 ? lim - vrel : 8;
+      uint32_t x[8];
+      const bool bp = e.x >> 31;
+      if (bp) {
+        const uint32_t rel = e.y - (uint32_t)d.org + kk * (uint32_t)W;
+        if (rel + (uint32_t)W + 8u <= staged) {
+          unpack8<W>(s_stage, rel, x);
+        } else {
+          // a payload cut short by the end of the stream: bytes that are not there read as zero
+          for (int j = 0; j < 8; j++)
+            x[j] = extract_bits(c.in + d.in_off, (uint32_t)d.avail, e.y, (uint64_t)(kk * 8u + (uint32_t)j) * (uint32_t)W, W);
+        }
       } else {
-        // a payload cut short by the end of the stream: bytes that are not there read as zero
-        for (int j = 0; j < 8; j++)
-          x[j] = extract_bits(c.in + d.in_off, (uint32_t)d.avail, e.y, (uint64_t)(kk * 8u + (uint32_t)j) * (uint32_t)W, W);
-      }
-    } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) x[j] = e.y;
-    }
-    const int64_t oidx = d.out_elem + d.t0 + vrel;
+        for (int j = 0; j < 8; j++) x[j] = e.y;
+      }
+      oidx = d.out_elem + d.t0 + vrel;
 
-    if (MODE == 0) {
-      int32_t *outp = (is_def ? a.def_out : a.rep_out) + oidx;
-      const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+      if (MODE == 0) {
+        const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
 #pragma unroll
-      for (int j = 0; j < 8; j++) n_flag += (j >= j0 && j < j1) && (is_def ? (x[j] != cmp) : (x[j] == cmp));
-      store_item(reinterpret_cast<uint32_t *>(outp), x, j0, j1);
-    } else if (MODE == 4 || MODE == 8) {
-      if (ident) {
-        // int32(value) / int64(value): the unpacked numbers are zero extended (encodingread.go:160, :202)
-        if (MODE == 4) store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, x, j0, j1);
-        else {
-          uint64_t y[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) y[j] = x[j];
-          store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
+        for (int j = 0; j < 8; j++) {
+          n_flag += (j >= j0 && j < j1) && (is_def ? (x[j] != cmp) : (x[j] == cmp));
+          out4[j] = x[j];
         }
-        continue;
-      }
-      if (bp ? check_bp : true) {
+      } else if (MODE == 4 || MODE == 8) {
+        if (ident) {
+          // int32(value) / int64(value): the unpacked numbers are zero extended (encodingread.go:160, :202)
+          if (MODE == 4) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (x[j] >= (uint32_t)a.dict_n) { bad_index = bad_index || (j >= j0 && j < j1); x[j] = 0; }
-      }
-      if (MODE == 4) {
-        uint32_t y[8];
-        dict_lookup8<DMODE, uint32_t>(a, s_dict, x, y);
-        store_item(reinterpret_cast<uint32_t *>(a.values_out) + oidx, y, j0, j1);
+            for (int j = 0; j < 8; j++) out4[j] = x[j];
+          } else {
+            uint64_t y[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) y[j] = x[j];
+            store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
+          }
+        } else {
+          if (bp ? check_bp : true) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+              if (x[j] >= (uint32_t)a.dict_n) { bad_index = bad_index || (j >= j0 && j < j1); x[j] = 0; }
+          }
+          if (MODE == 4) {
+            dict_lookup8<DMODE, uint32_t>(a, s_dict, x, out4);
+          } else {
+            uint64_t y[8];
+            dict_lookup8<DMODE, uint64_t>(a, s_dict, x, y);
+            store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
+          }
+        }
       } else {
-        uint64_t y[8];
-        dict_lookup8<DMODE, uint64_t>(a, s_dict, x, y);
-        store_item(reinterpret_cast<uint64_t *>(a.values_out) + oidx, y, j0, j1);
-      }
-    } else {
-      const int esz = c.elem_size;
-      if (ident) {
-        for (int j = j0; j < j1; j++) {
-          uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
-          for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(x[j] >> (8 * bb)) : (uint8_t)0;
+        const int esz = c.elem_size;
+        if (ident) {
+          for (int j = j0; j < j1; j++) {
+            uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
+            for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(x[j] >> (8 * bb)) : (uint8_t)0;
+          }
+        } else {
+          for (int j = j0; j < j1; j++) {
+            uint32_t idx = x[j];
+            if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
+            uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
+            const bool in_lds = DMODE == 1 || (DMODE == 2 && idx < (uint32_t)a.dict_lds_n);
+            if (in_lds) { const uint8_t *src = s_dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
+            else { const uint8_t *src = a.dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
+          }
         }
-        continue;
-      }
-      for (int j = j0; j < j1; j++) {
-        uint32_t idx = x[j];
-        if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-        uint8_t *dst = a.values_out + (size_t)(oidx + j) * esz;
-        const bool in_lds = DMODE == 1 || (DMODE == 2 && idx < (uint32_t)a.dict_lds_n);
-        if (in_lds) { const uint8_t *src = s_dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
-        else { const uint8_t *src = a.dict + (size_t)idx * esz; for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb]; }
       }
     }
+    if ((MODE == 0 || MODE == 4) && active) {
+      uint32_t *arr = MODE == 0 ? reinterpret_cast<uint32_t *>(is_def ? a.def_out : a.rep_out) : reinterpret_cast<uint32_t *>(a.values_out);
+      store_item(arr + oidx, out4, j0, j1);
+    }
+  }
+}
+
+// The work on one tile once its run slice and packed bytes are in LDS (or, for a tile beyond the LDS budget, straight
+// from global memory): the items, then the tile's counts or its error.
+template <int MODE, int DMODE, int GT>
+__device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc &d, const RunEntry *s_runs, const int *s_seg,
+                                             uint16_t *s_mark, const uint32_t *s_stage, const uint8_t *s_dict, int gtid) {
+  const ChunkCtx &c = a.c;
+  const int esz = c.elem_size;
+  const bool valid = (d.flags & 1) != 0;
+  const bool in_lds = (d.flags & 2) != 0;
+  const RunEntry *gruns = c.runs + d.run0;
+  const uint8_t *sbase = c.in + d.in_off;
+  const uint32_t staged = (uint32_t)((d.span + 8 + 15) >> 4) * 16u;
+  int n_flag = 0;  // levels: nulls or rows counted by this thread
+  bool bad_index = false;
+  if (in_lds) {
+    switch (__builtin_amdgcn_readfirstlane(d.w)) {
+#define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
+      PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
+      PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
+      PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
+      PQD_CASE(25) PQD_CASE(26) PQD_CASE(27) PQD_CASE(28) PQD_CASE(29) PQD_CASE(30) PQD_CASE(31) PQD_CASE(32)
+#undef PQD_CASE
+      default: break;
+    }
+  } else if (valid) {
+    // tiles with more runs or bytes than the LDS budget: four values per lane straight from global memory
+    for (int it = 0; it < kTile / (GT * 4); it++) {
+      const int rel = it * GT * 4 + gtid * 4;
+      const int v = d.t0 + rel;
+      if (v >= d.t1) continue;
+      const int n4 = d.t1 - v < 4 ? d.t1 - v : 4;
+      uint32_t x[4] = {0, 0, 0, 0};
+      decode4(gruns, d.nr, v, n4, sbase, (uint32_t)d.avail, d.w, x);
+      if (MODE == 0) {
+        const bool is_def = (d.flags & 4) != 0;
+        int32_t *outp = (is_def ? a.def_out : a.rep_out) + d.out_elem + v;
+        const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+        for (int j = 0; j < n4; j++) {
+          n_flag += is_def ? (x[j] != cmp) : (x[j] == cmp);
+          outp[j] = (int32_t)x[j];
+        }
+      } else {
+        for (int j = 0; j < n4; j++) {
+          uint32_t idx = x[j];
+          uint8_t *dst = a.values_out + (size_t)(d.out_elem + v + j) * esz;
+          if (d.flags & 8) {
+            for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(idx >> (8 * bb)) : (uint8_t)0;
+            continue;
+          }
+          if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
+          const uint8_t *src = a.dict + (size_t)idx * esz;
+          if (MODE == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+          else if (MODE == 8) *reinterpret_cast<uint64_t *>(dst) = *reinterpret_cast<const uint64_t *>(src);
+          else for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb];
+        }
+      }
+    }
+  }
+
+  if (MODE == 0) {
+    // wave reduction, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
+    if ((gtid & 63) == 0 && n_flag) atomicAdd((d.flags & 4) ? &c.state[d.page].n_nulls : &c.state[d.page].n_rows, n_flag);
+  } else {
+    if (bad_index) set_status(&c.state[d.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
   }
 }
 
@@ -369,10 +447,9 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
   const int g = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
   const int gtid = G == 1 ? (int)threadIdx.x : (int)threadIdx.x % GT;
   uint8_t *area = lds + a.dict_lds_bytes + g * a.group_bytes;
-  RunEntry *s_runs = reinterpret_cast<RunEntry *>(area);
-  int *s_seg = reinterpret_cast<int *>(area + runs_lds_bytes(a.runs_cap));
-  uint16_t *s_mark = reinterpret_cast<uint16_t *>(area + runs_lds_bytes(a.runs_cap) + kSegBytes);
-  uint32_t *s_stage = reinterpret_cast<uint32_t *>(area + runs_lds_bytes(a.runs_cap) + kSegBytes + marks_lds_bytes(a.mark_cap));
+  int *s_seg = reinterpret_cast<int *>(area);
+  uint16_t *s_mark = reinterpret_cast<uint16_t *>(area + kSegBytes);
+  RunEntry *s_runs = reinterpret_cast<RunEntry *>(area + kSegBytes + marks_lds_bytes(a.mark_cap));
   const uint8_t *s_dict = lds;
   const ChunkCtx &c = a.c;
   const int esz = c.elem_size;
@@ -393,107 +470,69 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
     const TileDesc d = d_next;
     d_next.flags = 0;
     if (tile + stride < a.n_tiles) d_next = descs[tile + stride];  // in flight while this tile is expanded
-    const bool valid = (d.flags & 1) != 0;
     const bool in_lds = (d.flags & 2) != 0;
     const RunEntry *gruns = c.runs + d.run0;
     const uint8_t *sbase = c.in + d.in_off;
     const int nvec = (d.span + 8 + 15) >> 4;
-    const uint32_t staged = (uint32_t)nvec * 16u;
+    // the packed bytes follow the tile's run slice (nr entries and the sentinel) in the pool
+    uint32_t *s_stage = reinterpret_cast<uint32_t *>(s_runs + d.nr + 1);
 
     __syncthreads();  // the previous tile is done with LDS (first pass: dictionary and marks are in place after the next one)
     if (in_lds) {
-      // run slice, segment table, marks and packed bytes: all loads issued before the one barrier
+      // run slice, segment table, marks and packed bytes.  Every thread's first run entry and first two vectors of
+      // packed bytes - all there is, for most tiles - are asked for together, before anything waits: one trip to
+      // memory per tile, not one per kind of thing.
       const uint32_t item_lo = d.item_lo, item_hi = d.item_lo + (uint32_t)d.n_items;
-      for (int i = gtid; i < d.nr; i += GT) {
-        const RunEntry e = gruns[i];
-        s_runs[i] = e;
-        if (i < d.nr - 1) {
-          // the 64-item segments whose first item run i holds
-          const uint32_t zn = gruns[i + 1].z;
-          const int ia = e.z <= item_lo ? 0 : (int)(e.z - item_lo);
-          const int ib = zn >= item_hi ? d.n_items : (zn <= item_lo ? 0 : (int)(zn - item_lo));
-          for (int j = (ia + 63) >> 6; (j << 6) < ib; j++) s_seg[j] = i;
-          // a mark at the run's first item (the previous tile's readers cleared theirs before the barrier above)
-          if (i >= 1 && e.z > item_lo && e.z < item_hi) s_mark[e.z - item_lo] = (uint16_t)i;
-        }
-      }
-      if (gtid == 0) s_runs[d.nr] = RunEntry{0x7FFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
-      for (int i = gtid; i < nvec; i += GT) {
-        const int sp0 = d.org + 16 * i;  // stream position of this vector
+      auto note_run = [&](int i, const RunEntry &e, uint32_t zn) {
+        // the 64-item segments whose first item run i holds
+        const int ia = e.z <= item_lo ? 0 : (int)(e.z - item_lo);
+        const int ib = zn >= item_hi ? d.n_items : (zn <= item_lo ? 0 : (int)(zn - item_lo));
+        for (int j = (ia + 63) >> 6; (j << 6) < ib; j++) s_seg[j] = i;
+        // a mark at the run's first item (the previous tile's readers cleared theirs before the barrier above)
+        if (i >= 1 && e.z > item_lo && e.z < item_hi) s_mark[e.z - item_lo] = (uint16_t)i;
+      };
+      auto stage_raw = [&](int i) {
         uint4 x = make_uint4(0, 0, 0, 0);
-        if (sp0 < d.avail) {
-          x = *reinterpret_cast<const uint4 *>(sbase + sp0);
-          const int left = d.avail - sp0;
-          if (left < 16) {
-            uint32_t wv[4] = {x.x, x.y, x.z, x.w};
+        if (i < nvec && d.org + 16 * i < d.avail) x = *reinterpret_cast<const uint4 *>(sbase + d.org + 16 * i);
+        return x;
+      };
+      auto stage_put = [&](int i, uint4 x) {
+        if (i >= nvec) return;
+        const int left = d.avail - (d.org + 16 * i);   // bytes of the stream in this vector; the rest reads as zero
+        if (left < 16) {
+          uint32_t wv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int lb = left - 4 * q;
-              if (lb <= 0) wv[q] = 0;
-              else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
-            }
-            x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+          for (int q = 0; q < 4; q++) {
+            const int lb = left - 4 * q;
+            if (lb <= 0) wv[q] = 0;
+            else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
           }
+          x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
         reinterpret_cast<uint4 *>(s_stage)[i] = x;
+      };
+      RunEntry e0 = {0u, 0u, 0u, 0u};
+      uint32_t zn0 = 0;
+      if (gtid < d.nr) e0 = gruns[gtid];
+      if (gtid < d.nr - 1) zn0 = gruns[gtid + 1].z;
+      const uint4 v0 = stage_raw(gtid), v1 = stage_raw(gtid + GT);
+      if (gtid < d.nr) {
+        s_runs[gtid] = e0;
+        if (gtid < d.nr - 1) note_run(gtid, e0, zn0);
       }
+      for (int i = gtid + GT; i < d.nr; i += GT) {
+        const RunEntry e = gruns[i];
+        s_runs[i] = e;
+        if (i < d.nr - 1) note_run(i, e, gruns[i + 1].z);
+      }
+      if (gtid == 0) s_runs[d.nr] = RunEntry{0x7FFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+      stage_put(gtid, v0);
+      stage_put(gtid + GT, v1);
+      for (int i = gtid + 2 * GT; i < nvec; i += GT) stage_put(i, stage_raw(i));
     }
     __syncthreads();
 
-    int n_flag = 0;  // levels: nulls or rows counted by this thread
-    bool bad_index = false;
-    if (in_lds) {
-      switch (__builtin_amdgcn_readfirstlane(d.w)) {
-#define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
-        PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
-        PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
-        PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
-        PQD_CASE(25) PQD_CASE(26) PQD_CASE(27) PQD_CASE(28) PQD_CASE(29) PQD_CASE(30) PQD_CASE(31) PQD_CASE(32)
-#undef PQD_CASE
-        default: break;
-      }
-    } else if (valid) {
-      // tiles with more runs or bytes than the LDS budget: four values per lane straight from global memory
-      for (int it = 0; it < kTile / (GT * 4); it++) {
-        const int rel = it * GT * 4 + gtid * 4;
-        const int v = d.t0 + rel;
-        if (v >= d.t1) continue;
-        const int n4 = d.t1 - v < 4 ? d.t1 - v : 4;
-        uint32_t x[4] = {0, 0, 0, 0};
-        decode4(gruns, d.nr, v, n4, sbase, (uint32_t)d.avail, d.w, x);
-        if (MODE == 0) {
-          const bool is_def = (d.flags & 4) != 0;
-          int32_t *outp = (is_def ? a.def_out : a.rep_out) + d.out_elem + v;
-          const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
-          for (int j = 0; j < n4; j++) {
-            n_flag += is_def ? (x[j] != cmp) : (x[j] == cmp);
-            outp[j] = (int32_t)x[j];
-          }
-        } else {
-          for (int j = 0; j < n4; j++) {
-            uint32_t idx = x[j];
-            uint8_t *dst = a.values_out + (size_t)(d.out_elem + v + j) * esz;
-            if (d.flags & 8) {
-              for (int bb = 0; bb < esz; bb++) dst[bb] = bb < 4 ? (uint8_t)(idx >> (8 * bb)) : (uint8_t)0;
-              continue;
-            }
-            if (idx >= (uint32_t)a.dict_n) { bad_index = true; idx = 0; }
-            const uint8_t *src = a.dict + (size_t)idx * esz;
-            if (MODE == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
-            else if (MODE == 8) *reinterpret_cast<uint64_t *>(dst) = *reinterpret_cast<const uint64_t *>(src);
-            else for (int bb = 0; bb < esz; bb++) dst[bb] = src[bb];
-          }
-        }
-      }
-    }
-
-    if (MODE == 0) {
-      // wave reduction, one atomic per wave
-      for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
-      if ((gtid & 63) == 0 && n_flag) atomicAdd((d.flags & 4) ? &c.state[d.page].n_nulls : &c.state[d.page].n_rows, n_flag);
-    } else {
-      if (bad_index) set_status(&c.state[d.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
-    }
+    process_tile<MODE, DMODE, GT>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid);
   }
 }
 
@@ -507,11 +546,13 @@ static int clamp_stage(int stage_bytes) {
   return sb;
 }
 
-static void set_group_layout(ExpandArgs &a, int runs_cap, int stage_bytes) {
-  a.runs_cap = runs_cap;
-  a.mark_cap = kTile / 8 + runs_cap + 8;
-  a.stage_bytes = clamp_stage(stage_bytes);
-  a.group_bytes = runs_lds_bytes(a.runs_cap) + kSegBytes + marks_lds_bytes(a.mark_cap) + a.stage_bytes;
+// run_room: run-slice entries the pool has room for beside a tile's full complement of packed bytes
+static void set_group_layout(ExpandArgs &a, int run_room, int stage_bytes) {
+  a.pool_bytes = runs_lds_bytes(run_room) + clamp_stage(stage_bytes);
+  a.runs_cap = a.pool_bytes / (int)sizeof(RunEntry) - 3;
+  if (a.runs_cap > kRunSlice) a.runs_cap = kRunSlice;
+  a.mark_cap = kTile / 8 + a.runs_cap + 8;
+  a.group_bytes = kSegBytes + marks_lds_bytes(a.mark_cap) + a.pool_bytes;
 }
 
 template <class K>
@@ -566,7 +607,7 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
     const bool lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;
     a.dict_lds_n = lds ? dict_n : 0;
     a.dict_lds_bytes = lds ? (int)dict_bytes : 0;
-    set_group_layout(a, kRunSlice, stage_bytes);
+    set_group_layout(a, 254, stage_bytes);
     const size_t shmem = (size_t)a.dict_lds_bytes + a.group_bytes;
     int per_cu = (int)(kLdsTotal / (shmem + 512));
     if (per_cu > 8) per_cu = 8;
