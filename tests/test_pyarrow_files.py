@@ -213,3 +213,68 @@ def test_gpu_matches_pyarrow_and_oracle(parquet_file, oracle):
             assert np.array_equal(g.offsets, o.offsets) and np.array_equal(g.bytes, o.bytes), name
         check_table(g, f, rg, name, ptype, max_def, num_values)
     dec.close()
+
+
+def _v2_bool_chunks(tmp_path, nulls):
+    """A BOOLEAN column written by pyarrow with v2 data pages and no encoding named: pyarrow then picks Encoding_RLE
+    for the values (bit width 1 in its reading of the format)."""
+    rng = np.random.default_rng(5 + nulls)
+    n = 20000
+    vals = np.repeat(rng.integers(0, 2, n // 8 + 1).astype(bool), rng.integers(1, 16, n // 8 + 1))[:n]
+    arr = pa.array(vals, mask=(rng.random(len(vals)) < 0.15) if nulls else None)
+    path = str(tmp_path / ("b%d.parquet" % nulls))
+    pq_.write_table(pa.table({"b": arr}), path, compression="NONE", data_page_version="2.0", data_page_size=4096,
+                    write_statistics=False, use_dictionary=False)
+    return column_chunks(path)[1]
+
+
+def _check_v2_bool(decode, oracle, tmp_path):
+    import parquet_go_amd as pq
+    seen = set()
+    for nulls in (0, 1):
+        for name, ptype, tl, max_def, max_rep, chunk, num_values, rg, ci in _v2_bool_chunks(tmp_path, nulls):
+            pages = pq.scan_pages(chunk, num_values)
+            seen.update(int(e) for e in pages["encoding"])
+            o = oracle.read_chunk(chunk, pages, PHYS[ptype], tl, max_def, max_rep)
+            # The reference reads Encoding_RLE values with the column's type length as the bit width (layout/page.go:657-667),
+            # which is 0 for BOOLEAN: the oracle says what comes of that, and the GPU path has to say the same
+            if decode is not None:
+                g = decode(chunk, pages, PHYS[ptype], tl, max_def, max_rep)
+                assert (g.status, g.bad_page) == (o.status, o.bad_page)
+                if o.status == 0:
+                    assert (g.n_slots, g.n_rows, g.n_nulls) == (o.n_slots, o.n_rows, o.n_nulls)
+                    assert np.array_equal(g.def_levels, o.def_levels) and np.array_equal(g.values, o.values)
+    assert 3 in seen, "pyarrow did not write Encoding_RLE values: %r" % (seen,)
+
+
+def test_oracle_reads_pyarrow_v2_default_bool(oracle, tmp_path):
+    _check_v2_bool(None, oracle, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_pyarrow_v2_default_bool(oracle, tmp_path):
+    import parquet_go_amd as pq
+    dec = pq.Decoder(0)
+    try:
+        _check_v2_bool(dec.decode, oracle, tmp_path)
+    finally:
+        dec.close()
+
+
+def test_scan_pages_reports_capacity_and_the_wrapper_grows(parquet_file):
+    """pqd_scan_pages with room for fewer descriptors than the chunk has pages: PQD_ERR_CAPACITY and the number of
+    pages it got to; the Python wrapper retries with more room."""
+    import ctypes
+    import parquet_go_amd as pq
+    f, chunks = column_chunks(parquet_file)
+    name, ptype, tl, max_def, max_rep, chunk, num_values, rg, ci = max(chunks, key=lambda c: len(c[5]))
+    pages = pq.scan_pages(chunk, num_values)
+    assert len(pages) > 2
+    lib = pq.lib()
+    small = np.zeros(2, pq.PAGE_DESC_DTYPE)
+    n = ctypes.c_int32(0)
+    buf = (ctypes.c_uint8 * len(chunk)).from_buffer_copy(chunk)
+    rc = lib.pqd_scan_pages(buf, ctypes.c_size_t(len(chunk)), ctypes.c_int64(num_values),
+                            small.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(2), ctypes.byref(n))
+    assert rc == pq.binding.ERR_CAPACITY
+    assert np.array_equal(small, pages[:2])
