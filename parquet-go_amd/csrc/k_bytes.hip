@@ -288,7 +288,9 @@ constexpr int kChainMax = 1024;  // longest string the in-order chain kernel kee
 // Per page: the first prefix length is ignored (encodingread.go:427), prefix lengths are range checked, and pages
 // holding a string longer than kChainMax are marked for the parent-chain kernels (flag 1); the others go through
 // k_dba_chain (flag 0).
-__global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix, const uint64_t *pairs, int32_t *page_flag) {
+// For pages of the first kind it also leaves the smallest prefix length of every 64 strings in bmin[dense_base + block]
+// (the page's own stretch of an array with one int32 per value): k_dba_chain skips by them when it looks backwards.
+__global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix, const uint64_t *pairs, int32_t *page_flag, int32_t *bmin) {
   __shared__ int s_bad, s_long;
   const int d = blockIdx.x, tid = threadIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
@@ -301,12 +303,21 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
   if (tid == 0) { prefix[base] = 0; s_bad = 0; s_long = 0; }
   __syncthreads();
   int bad = 0, lng = 0;
-  for (int i = tid; i < cnt; i += 256) {
-    const int64_t pi = prefix[base + i];
-    if (pi < 0 || pi > kMaxStrLen) bad = 1;
-    else if (pi + (int64_t)(pairs[base + i] >> 40) > kChainMax) lng = 1;
-    // a prefix longer than the previous string is a slice out of range in the reference (encodingread.go:430)
-    if (i > 0 && pi > (i == 1 ? 0 : prefix[base + i - 1]) + (int64_t)(pairs[base + i - 1] >> 40)) bad = 1;
+  for (int i0 = 0; i0 < cnt; i0 += 256) {
+    const int i = i0 + tid;
+    int64_t pmin = 0x7fffffff;
+    if (i < cnt) {
+      const int64_t pi = prefix[base + i];
+      if (pi < 0 || pi > kMaxStrLen) bad = 1;
+      else if (pi + (int64_t)(pairs[base + i] >> 40) > kChainMax) lng = 1;
+      // a prefix longer than the previous string is a slice out of range in the reference (encodingread.go:430)
+      if (i > 0 && pi > (i == 1 ? 0 : prefix[base + i - 1]) + (int64_t)(pairs[base + i - 1] >> 40)) bad = 1;
+      pmin = pi < 0 ? 0 : (pi > 0x7fffffff ? 0x7fffffff : pi);
+    }
+    // (a wavefront holds the 64 strings of one block)
+    int v = (int)pmin;
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(v, o); v = y < v ? y : v; }
+    if ((tid & 63) == 0 && i < cnt) bmin[base + (i >> 6)] = v;
   }
   if (bad) s_bad = 1;
   if (lng) s_long = 1;
@@ -322,8 +333,9 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 // page and so do the outputs, so only the two lengths are per-string inputs.
 //
 // A string with prefix length 0 does not depend on its predecessor: the page is cut into kChainWaves ranges that
-// each begin at such a string (the first one at or after an even split), one wavefront per range.  Data without
-// such strings leaves a page to one wavefront, at the speed of a single chain.
+// each begin at such a string (the first one at or after an even split), one wavefront per range.  Large pages
+// without such strings near the split (sorted keys: every string continues the one before) are cut at the split
+// itself, and the wavefront first works out the bytes its first string shares with the string before it.
 //
 // A range is walked in batches of 64 strings (lane u holds the lengths of string u): the suffix bytes of the next
 // half batch and the lengths of the batch after the next are in flight while the current half is chained together.
@@ -351,9 +363,10 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane
 
 __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
                                                                 const uint64_t *__restrict__ pairs, const int64_t *__restrict__ doff,
-                                                                const int32_t *__restrict__ page_flag, uint8_t *__restrict__ bytes_out,
-                                                                const int64_t *__restrict__ total, int64_t cap) {
+                                                                const int32_t *__restrict__ page_flag, const int32_t *__restrict__ bmin_all,
+                                                                uint8_t *__restrict__ bytes_out, const int64_t *__restrict__ total, int64_t cap) {
   __shared__ uint8_t s_cur_all[kChainWaves][kChainMax + 64];
+  __shared__ int s_cut[kChainWaves];
   __shared__ __align__(16) uint8_t s_stage_all[kChainWaves][kStageBytes];
   __shared__ int s_bnd[kChainWaves + 1];
   if (*total > cap) return;
@@ -368,17 +381,32 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
   const int64_t base = uniform64(ps->dense_base);
   const int cnt = __builtin_amdgcn_readfirstlane(ps->cnt);
 
-  // this wave's range [r_lo, r_hi)
+  // this wave's range [r_lo, r_hi): from the first string with prefix length 0 at or after an even split when there
+  // is one close by; otherwise (large pages) from the split itself, the start state then being worked out by looking
+  // backwards (below)
   {
-    int lo = cnt;
+    int lo = cnt, cut = 0;
     const int from = wave == 0 ? 0 : (int)((int64_t)cnt * wave / kChainWaves);
-    for (int j0 = from; j0 < cnt && lo == cnt; j0 += 64) {
+    const bool may_cut = cnt >= kChainWaves * 512;      // (boundaries stay in order: the search below covers 256 strings)
+    const int upto = may_cut ? (from + 256 < cnt ? from + 256 : cnt) : cnt;
+    for (int j0 = from; j0 < upto && lo == cnt; j0 += 64) {
       const int j = j0 + lane;
-      const bool zero = j < cnt && (j == 0 || prefix[base + j] == 0);
+      const bool zero = j < upto && (j == 0 || prefix[base + j] == 0);
       const uint64_t m = __ballot(zero);
       if (m) lo = j0 + (int)__builtin_ctzll(m);
     }
-    if (lane == 0) s_bnd[wave] = lo;
+    if (lo == cnt && may_cut && from < cnt) {
+      if (prefix[base + from] <= 64) { lo = from; cut = 1; }
+      else {
+        for (int j0 = upto; j0 < cnt && lo == cnt; j0 += 64) {
+          const int j = j0 + lane;
+          const bool zero = j < cnt && prefix[base + j] == 0;
+          const uint64_t m = __ballot(zero);
+          if (m) lo = j0 + (int)__builtin_ctzll(m);
+        }
+      }
+    }
+    if (lane == 0) { s_bnd[wave] = lo; s_cut[wave] = cut; }
     if (threadIdx.x == 0) s_bnd[kChainWaves] = cnt;
   }
   __syncthreads();
@@ -434,6 +462,45 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
   // LDS and memory chunks coincide, and the partial chunks at both ends go out bytewise.
   // (lanes beyond the batch hold lengths 0, 0: nothing is kept for them)
   uint32_t cur = 0;   // byte `lane` of the previous string
+  if (__builtin_amdgcn_readfirstlane(s_cut[wave])) {
+    // The range starts in the middle of a chain: lane k < P needs byte k of the string before the range.  That byte
+    // belongs to the nearest earlier string whose prefix length is <= k (byte k - prefix of its suffix).  Looking
+    // backwards, every string whose prefix length is below the smallest seen so far (m) owns the bytes [its prefix
+    // length, m); blocks of 64 strings whose smallest prefix length is not below m are skipped by the minima that
+    // k_dba_prepare left.  The page's first string has prefix length 0, so m reaches 0.
+    const int32_t *bmin = bmin_all + base;
+    int m = (int)uniform64(prefix[base + r_lo]);     // (<= 64)
+    int own_j = 0, own_p = 0;
+    int blk = (r_lo - 1) >> 6;
+    while (m > 0) {
+      const int j = 64 * blk + lane;
+      int pj = 0x7fffffff;
+      if (j < r_lo) pj = j == 0 ? 0 : (int)prefix[base + j];
+      for (;;) {
+        const uint64_t mk = __ballot(pj < m);
+        if (!mk) break;
+        const int u = 63 - (int)__builtin_clzll(mk);
+        const int pu = __builtin_amdgcn_readlane(pj, u);
+        if (lane >= pu && lane < m) { own_j = 64 * blk + u; own_p = pu; }
+        m = pu;
+        if (lane >= u) pj = 0x7fffffff;            // the strings from u on are behind us
+      }
+      if (m == 0 || blk == 0) break;
+      int b0 = blk - 1;                              // the nearest earlier block holding a prefix length below m
+      for (;;) {
+        const int nb = b0 - lane;
+        const uint64_t hk = __ballot(nb >= 0 && bmin[nb] < m);
+        if (hk) { blk = b0 - (int)__builtin_ctzll(hk); break; }
+        b0 -= 64;
+        if (b0 < 0) { blk = 0; break; }              // (block 0 holds the page's first string: never reached)
+      }
+    }
+    if (lane < (int)uniform64(prefix[base + r_lo])) {
+      const uint64_t pr = pairs[base + own_j];
+      const int64_t at = (int64_t)(pr & kSrcMask) + (lane - own_p);
+      cur = at < c.in_len ? c.in[at] : 0u;
+    }
+  }
   auto chain_half = [&](const DbaBatch &b, int half, const uint32_t ld[32], uint32_t out_off) {
     uint8_t *dst = b.out + out_off;
     const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(dst) & 15u;
@@ -682,10 +749,10 @@ hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t
                               hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (phase == 0) {
-    hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag);
+    hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag, parent);
     hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent, page_flag);
   } else {
-    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, bytes_out, total, cap);
+    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, parent, bytes_out, total, cap);
     hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out, total, cap);
   }
   return hipGetLastError();

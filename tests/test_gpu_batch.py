@@ -258,3 +258,17 @@ def test_a_call_on_a_handle_that_was_never_waited_for(oracle):
         same_table(d.fetch(), oracle.read_chunk(a[0], a[1], pg.INT32))
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("page_values", [5000, 70000])
+def test_delta_byte_array_pages_without_a_restart_are_cut_anyway(dec, oracle, page_values):
+    # sorted keys (a zero-padded counter and a suffix): no string inside a page has prefix length 0, so the only place
+    # where a chain restarts is the page's first string; pages of 4096 strings and more are cut into ranges at
+    # arbitrary strings, each range working out what its first string shares with the string before it
+    from gen import pqgen
+    chunk, pages = pqgen.strings_chunk(0xBEEF, 3 * page_values + 17, page_values, 3)
+    g = dec.decode(chunk, pages, pg.BYTE_ARRAY)
+    o = oracle.read_chunk(chunk, pages, pg.BYTE_ARRAY)
+    assert g.status == o.status == 0
+    assert np.array_equal(g.offsets, o.offsets)
+    assert np.array_equal(g.bytes, o.bytes)
