@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--list-slots", type=int, default=128 << 20)
     ap.add_argument("--string-values", type=int, default=100_000_000)
     ap.add_argument("--row-groups", type=int, default=1024, help="configs[4]: row groups of 1 Mi level slots over all GPUs")
+    ap.add_argument("--rg-group", type=int, default=64, help="configs[4] row-group leg: chunks per decode call")
     ap.add_argument("--only-extra", type=str, default="", help="comma separated names: run only these extras (development aid)")
     ap.add_argument("--iso-reps", type=int, default=3, help="serial launches per width for the isolated kernel durations")
     return ap.parse_args()
@@ -173,10 +174,10 @@ def main():
         submit(item, dec)
         return finish(item, dec, collect)
 
-    # --depth sets of handles: a step submits its chunks on the next set and only then collects the set that was
-    # submitted --depth steps earlier, so the serial run-header walk of one step hides behind the expansion of the
-    # previous one (a reader streaming row groups works the same way).  Every step is complete before the timed
-    # region ends: drain() waits for the sets still in flight.
+    # --depth sets of handles: a step takes the next set; each of its handles first collects the chunk it was given
+    # --depth steps earlier, so the serial run-header walk of one step hides behind the expansion of the earlier
+    # ones (a reader streaming row groups works the same way).  Every step is complete before the timed region
+    # ends: drain() waits for the sets still in flight.
     depth = max(1, args.depth)
     sets = [decs] + [[pq.Decoder(local_rank, profiling=True) for _ in range(n_handles)] for _ in range(depth - 1)]
     pending = [[] for _ in range(depth)]
@@ -188,20 +189,30 @@ def main():
         pending[k] = []
 
     def step(collect=False):
+        # Every handle works like one column's goroutine in the reference (reader/reader.go:306-327): it waits for its own
+        # previous chunk and takes the next one at once, so its run-header walk starts while the other handles' chunks of
+        # the earlier steps are still being expanded (collecting the whole set first leaves the GPU with nothing but
+        # serial walks to do until the first of them ends).
         k = step_no[0] % depth
         step_no[0] += 1
         for g in range(0, len(work), n_handles):
-            collect_set(k, collect)
             group = work[g:g + n_handles]
+            prev = {id(d): item for item, d in pending[k]}
+            pending[k] = []
             for item, d in zip(group, sets[k]):
+                if id(d) in prev:
+                    finish(prev.pop(id(d)), d, collect)
                 submit(item, d)
                 pending[k].append((item, d))
+            for d in sets[k]:   # handles the group did not use (a last group smaller than the set)
+                if id(d) in prev:
+                    finish(prev.pop(id(d)), d, collect)
         if depth == 1:
             collect_set(k, collect)
 
     def drain(collect=False):
-        for k in range(depth):
-            collect_set(k, collect)
+        for j in range(depth):
+            collect_set((step_no[0] + j) % depth, collect)
 
     # ---- verification against the CPU oracle (untimed) + CPU baseline on a bounded sample ----
     cpu = None
@@ -577,7 +588,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
                (pq.INT64,), lambda n: n * per_rg * 8, 8,
                "configs[2] as %d row-group chunks of %d Mi values (pages of 128 Ki values)" % (rg_delta, per_rg >> 20))
     strong_leg("list_int64_row_groups", args.row_groups, lambda k: pqgen.list_chunk(0x5EED2000 + k, 1 << 20, 128 << 10),
-               (pq.INT64, 0, 3, 1), lambda n: n * (1 << 20) * 16, 16,
+               (pq.INT64, 0, 3, 1), lambda n: n * (1 << 20) * 16, args.rg_group,
                "configs[4] as stated: %d row groups of 1 Mi level slots (8 pages of 128 Ki slots each), optional list<optional int64>, "
                "PLAIN values; output = rep + def + slot-aligned values" % args.row_groups)
 

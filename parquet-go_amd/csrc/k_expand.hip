@@ -431,6 +431,107 @@ __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc
   }
 }
 
+// What a thread asks for first when a tile is staged: its first run entry (and the item count behind it) and its first
+// two vectors of packed bytes - all there is, for most tiles.  Asked for together, before anything waits: one trip to
+// memory per tile, not one per kind of thing.
+struct TileLoads {
+  RunEntry e0;
+  uint32_t zn0;
+  uint4 v0, v1;
+};
+
+__device__ __forceinline__ uint4 stage_raw(const TileDesc &d, const uint8_t *sbase, int nvec, int i) {
+  uint4 x = make_uint4(0, 0, 0, 0);
+  if (i < nvec && d.org + 16 * i < d.avail) x = *reinterpret_cast<const uint4 *>(sbase + d.org + 16 * i);
+  return x;
+}
+
+template <int GT>
+__device__ __forceinline__ void tile_issue_loads(const ExpandArgs &a, const TileDesc &d, int gtid, TileLoads &pf) {
+  pf.e0 = RunEntry{0u, 0u, 0u, 0u};
+  pf.zn0 = 0;
+  pf.v0 = pf.v1 = make_uint4(0, 0, 0, 0);
+  if ((d.flags & 2) == 0) return;
+  const RunEntry *gruns = a.c.runs + d.run0;
+  const uint8_t *sbase = a.c.in + d.in_off;
+  const int nvec = (d.span + 8 + 15) >> 4;
+  if (gtid < d.nr) pf.e0 = gruns[gtid];
+  if (gtid < d.nr - 1) pf.zn0 = gruns[gtid + 1].z;
+  pf.v0 = stage_raw(d, sbase, nvec, gtid);
+  pf.v1 = stage_raw(d, sbase, nvec, gtid + GT);
+}
+
+// Run slice, segment table, marks and packed bytes of a tile into LDS: what tile_issue_loads asked for, then whatever a
+// tile of many runs or many bytes holds beyond that.
+template <int GT>
+__device__ __forceinline__ void tile_stage(const ExpandArgs &a, const TileDesc &d, int gtid, const TileLoads &pf, RunEntry *s_runs,
+                                           int *s_seg, uint16_t *s_mark) {
+  if ((d.flags & 2) == 0) return;
+  const RunEntry *gruns = a.c.runs + d.run0;
+  const uint8_t *sbase = a.c.in + d.in_off;
+  const int nvec = (d.span + 8 + 15) >> 4;
+  // the packed bytes follow the tile's run slice (nr entries and the sentinel) in the pool
+  uint32_t *s_stage = reinterpret_cast<uint32_t *>(s_runs + d.nr + 1);
+  const uint32_t item_lo = d.item_lo, item_hi = d.item_lo + (uint32_t)d.n_items;
+  auto note_run = [&](int i, const RunEntry &e, uint32_t zn) {
+    // the 64-item segments whose first item run i holds
+    const int ia = e.z <= item_lo ? 0 : (int)(e.z - item_lo);
+    const int ib = zn >= item_hi ? d.n_items : (zn <= item_lo ? 0 : (int)(zn - item_lo));
+    for (int j = (ia + 63) >> 6; (j << 6) < ib; j++) s_seg[j] = i;
+    // a mark at the run's first item (the previous tile's readers cleared theirs before the barrier in front of this)
+    if (i >= 1 && e.z > item_lo && e.z < item_hi) s_mark[e.z - item_lo] = (uint16_t)i;
+  };
+  auto stage_put = [&](int i, uint4 x) {
+    if (i >= nvec) return;
+    const int left = d.avail - (d.org + 16 * i);   // bytes of the stream in this vector; the rest reads as zero
+    if (left < 16) {
+      uint32_t wv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int lb = left - 4 * q;
+        if (lb <= 0) wv[q] = 0;
+        else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
+      }
+      x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    reinterpret_cast<uint4 *>(s_stage)[i] = x;
+  };
+  if (gtid < d.nr) {
+    s_runs[gtid] = pf.e0;
+    if (gtid < d.nr - 1) note_run(gtid, pf.e0, pf.zn0);
+  }
+  for (int i = gtid + GT; i < d.nr; i += GT) {
+    const RunEntry e = gruns[i];
+    s_runs[i] = e;
+    if (i < d.nr - 1) note_run(i, e, gruns[i + 1].z);
+  }
+  if (gtid == 0) s_runs[d.nr] = RunEntry{0x7FFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+  stage_put(gtid, pf.v0);
+  stage_put(gtid + GT, pf.v1);
+  for (int i = gtid + 2 * GT; i < nvec; i += GT) stage_put(i, stage_raw(d, sbase, nvec, i));
+}
+
+// Descriptors reach the expanding threads through a small ring in LDS, filled by plain loads two tiles ahead (a scalar
+// load would have to be waited for on the spot: the kernel keeps more scalars than there are registers for).
+constexpr int kRingSlots = 4;
+constexpr int kDescDwords = (int)(sizeof(TileDesc) / 4);
+constexpr int kDescUsed = 17;   // dwords of a descriptor that carry something
+static_assert(sizeof(TileDesc) == 128, "descriptor ring slots are 128 bytes");
+
+__device__ __forceinline__ TileDesc ring_read(const uint32_t *slot) {
+  uint32_t w[kDescUsed];
+#pragma unroll
+  for (int k = 0; k < kDescUsed; k++) w[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[k]);
+  TileDesc d;
+  d.in_off = (int64_t)(((uint64_t)w[1] << 32) | w[0]);
+  d.out_elem = (int64_t)(((uint64_t)w[3] << 32) | w[2]);
+  d.run0 = (int64_t)(((uint64_t)w[5] << 32) | w[4]);
+  d.item_lo = w[6]; d.n_items = (int32_t)w[7]; d.t0 = (int32_t)w[8]; d.t1 = (int32_t)w[9]; d.org = (int32_t)w[10];
+  d.span = (int32_t)w[11]; d.nr = (int32_t)w[12]; d.avail = (int32_t)w[13]; d.w = (int32_t)w[14]; d.flags = (int32_t)w[15];
+  d.page = (int32_t)w[16]; d.pad = 0;
+  return d;
+}
+
 // MODE 0: levels -> int32 (+ counts); MODE 4 / 8: dictionary gather of 4- / 8-byte elements;
 // MODE 1: dictionary gather of elem_size-byte elements (BOOLEAN, INT96, FIXED_LEN_BYTE_ARRAY)
 // G groups of GT threads per block; a group expands one tile at a time.
@@ -462,76 +563,38 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
   }
   for (int i = gtid; i < marks_lds_bytes(a.mark_cap) / 16; i += GT) reinterpret_cast<uint4 *>(s_mark)[i] = make_uint4(0, 0, 0, 0);
 
-  const int stride = (int)gridDim.x * G;
-  int tile = a.tile_lo + (int)blockIdx.x * G + g;
-  TileDesc d_next = {};
-  if (tile < a.n_tiles) d_next = descs[tile];
-  for (int base = a.tile_lo + (int)blockIdx.x * G; base < a.n_tiles; base += stride, tile += stride) {
-    const TileDesc d = d_next;
-    d_next.flags = 0;
-    if (tile + stride < a.n_tiles) d_next = descs[tile + stride];  // in flight while this tile is expanded
-    const bool in_lds = (d.flags & 2) != 0;
-    const RunEntry *gruns = c.runs + d.run0;
-    const uint8_t *sbase = c.in + d.in_off;
-    const int nvec = (d.span + 8 + 15) >> 4;
-    // the packed bytes follow the tile's run slice (nr entries and the sentinel) in the pool
+  // The tiles of this group: first, first + step, ...  Tile i's descriptor sits in ring slot i % kRingSlots.
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(area + a.group_bytes - kRingSlots * (int)sizeof(TileDesc));
+  const int first = a.tile_lo + (int)blockIdx.x * G + g, step = (int)gridDim.x * G;
+  const int n_my = first < a.n_tiles ? (a.n_tiles - first + step - 1) / step : 0;
+  // (the groups of a workgroup share its barriers: all of them make the rounds of the one with the most tiles)
+  const int first0 = a.tile_lo + (int)blockIdx.x * G;
+  const int n_rounds = first0 < a.n_tiles ? (a.n_tiles - first0 + step - 1) / step : 0;
+  auto desc_words = [&](int i) { return reinterpret_cast<const uint32_t *>(descs + (first + (int64_t)i * step)); };
+  if (gtid < kDescUsed && n_my > 0) s_ring[gtid] = desc_words(0)[gtid];
+  __syncthreads();   // (dictionary and marks are in place too)
+
+  // Software pipeline, one tile deep: the run entries and packed bytes of tile i + 1 are asked for before the values of
+  // tile i are worked out and stored, and the descriptor of tile i + 2 with them; both are looked at only at the top
+  // of the next round.  (Loads and stores of a wavefront complete in order: whatever a wavefront waits for, it also
+  // waits for the stores it issued before.  Asking after the stores would put a full trip to memory behind that wait.)
+  TileLoads pf;
+  tile_issue_loads<GT>(a, n_my > 0 ? ring_read(s_ring) : TileDesc{}, gtid, pf);
+  uint32_t dn = 0;
+  if (gtid < kDescUsed && 1 < n_my) dn = desc_words(1)[gtid];
+  for (int i = 0; i < n_rounds; i++) {
+    TileDesc d = {};
+    if (i < n_my) d = ring_read(s_ring + (i & (kRingSlots - 1)) * kDescDwords);
     uint32_t *s_stage = reinterpret_cast<uint32_t *>(s_runs + d.nr + 1);
-
-    __syncthreads();  // the previous tile is done with LDS (first pass: dictionary and marks are in place after the next one)
-    if (in_lds) {
-      // run slice, segment table, marks and packed bytes.  Every thread's first run entry and first two vectors of
-      // packed bytes - all there is, for most tiles - are asked for together, before anything waits: one trip to
-      // memory per tile, not one per kind of thing.
-      const uint32_t item_lo = d.item_lo, item_hi = d.item_lo + (uint32_t)d.n_items;
-      auto note_run = [&](int i, const RunEntry &e, uint32_t zn) {
-        // the 64-item segments whose first item run i holds
-        const int ia = e.z <= item_lo ? 0 : (int)(e.z - item_lo);
-        const int ib = zn >= item_hi ? d.n_items : (zn <= item_lo ? 0 : (int)(zn - item_lo));
-        for (int j = (ia + 63) >> 6; (j << 6) < ib; j++) s_seg[j] = i;
-        // a mark at the run's first item (the previous tile's readers cleared theirs before the barrier above)
-        if (i >= 1 && e.z > item_lo && e.z < item_hi) s_mark[e.z - item_lo] = (uint16_t)i;
-      };
-      auto stage_raw = [&](int i) {
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (i < nvec && d.org + 16 * i < d.avail) x = *reinterpret_cast<const uint4 *>(sbase + d.org + 16 * i);
-        return x;
-      };
-      auto stage_put = [&](int i, uint4 x) {
-        if (i >= nvec) return;
-        const int left = d.avail - (d.org + 16 * i);   // bytes of the stream in this vector; the rest reads as zero
-        if (left < 16) {
-          uint32_t wv[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int lb = left - 4 * q;
-            if (lb <= 0) wv[q] = 0;
-            else if (lb < 4) wv[q] &= (1u << (8 * lb)) - 1u;
-          }
-          x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-        }
-        reinterpret_cast<uint4 *>(s_stage)[i] = x;
-      };
-      RunEntry e0 = {0u, 0u, 0u, 0u};
-      uint32_t zn0 = 0;
-      if (gtid < d.nr) e0 = gruns[gtid];
-      if (gtid < d.nr - 1) zn0 = gruns[gtid + 1].z;
-      const uint4 v0 = stage_raw(gtid), v1 = stage_raw(gtid + GT);
-      if (gtid < d.nr) {
-        s_runs[gtid] = e0;
-        if (gtid < d.nr - 1) note_run(gtid, e0, zn0);
-      }
-      for (int i = gtid + GT; i < d.nr; i += GT) {
-        const RunEntry e = gruns[i];
-        s_runs[i] = e;
-        if (i < d.nr - 1) note_run(i, e, gruns[i + 1].z);
-      }
-      if (gtid == 0) s_runs[d.nr] = RunEntry{0x7FFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
-      stage_put(gtid, v0);
-      stage_put(gtid + GT, v1);
-      for (int i = gtid + 2 * GT; i < nvec; i += GT) stage_put(i, stage_raw(i));
-    }
+    __syncthreads();   // the previous tile is done with LDS
+    tile_stage<GT>(a, d, gtid, pf, s_runs, s_seg, s_mark);
+    if (gtid < kDescUsed && i + 1 < n_my) s_ring[((i + 1) & (kRingSlots - 1)) * kDescDwords + gtid] = dn;
     __syncthreads();
-
+    TileDesc d1 = {};
+    if (i + 1 < n_my) d1 = ring_read(s_ring + ((i + 1) & (kRingSlots - 1)) * kDescDwords);
+    tile_issue_loads<GT>(a, d1, gtid, pf);
+    dn = 0;
+    if (gtid < kDescUsed && i + 2 < n_my) dn = desc_words(i + 2)[gtid];
     process_tile<MODE, DMODE, GT>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid);
   }
 }
@@ -552,7 +615,7 @@ static void set_group_layout(ExpandArgs &a, int run_room, int stage_bytes) {
   a.runs_cap = a.pool_bytes / (int)sizeof(RunEntry) - 3;
   if (a.runs_cap > kRunSlice) a.runs_cap = kRunSlice;
   a.mark_cap = kTile / 8 + a.runs_cap + 8;
-  a.group_bytes = kSegBytes + marks_lds_bytes(a.mark_cap) + a.pool_bytes;
+  a.group_bytes = kSegBytes + marks_lds_bytes(a.mark_cap) + a.pool_bytes + kRingSlots * (int)sizeof(TileDesc);   // the descriptor ring comes last
 }
 
 template <class K>
