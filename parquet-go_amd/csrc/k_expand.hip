@@ -659,11 +659,11 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   const size_t dict_bytes = ((size_t)dict_n * esz + 15) / 16 * 16;
   const bool fixed48 = esz == 4 || esz == 8;
 
-  // shared_gpu: other chunks are being decoded at the same time.  The variant below that keeps the head of a
-  // mid-size dictionary in LDS takes a whole CU per workgroup and so shuts the other chunks' kernels out; with
-  // company the plain gather is the better neighbour.
-  // split_mode 0 / 1 pins the choice (tests), -1 leaves it to the situation
-  const bool no_split = split_mode >= 0 ? split_mode == 0 : shared_gpu;
+  // split_mode 0 / 1 pins the choice between the plain gather and the variant below that keeps the head of a mid-size
+  // dictionary in LDS (tests); -1 takes the latter, which also finishes a batch of chunks decoded side by side a little
+  // sooner (4.65 against 4.75 ms for the seven chunks of the benchmark) although each of its workgroups needs a whole CU.
+  (void)shared_gpu;
+  const bool no_split = split_mode == 0;
   if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024 || no_split) {
     // small dictionaries: whole dictionary in the LDS of every block, several 256-thread blocks per CU.
     // Large ones of other element sizes, and very large ones: gathered from L2 / HBM.
