@@ -6,14 +6,11 @@
 // layout/page.go:139-164 (dictionary gather), :835-888 (levels, null count), :925-927 (row count).
 #include <hip/hip_runtime.h>
 #include "pqd_kernels.h"
+#include "pqd_device.h"
 
 namespace pqd {
 
 __device__ __forceinline__ void set_status(int32_t *p, int code) { atomicCAS(p, 0, code); }  // first error wins
-
-struct U32x4Unaligned { uint32_t v[4]; } __attribute__((packed));
-struct U64x2Unaligned { uint64_t v[2]; } __attribute__((packed));
-struct U64Unaligned { uint64_t v; } __attribute__((packed));
 
 constexpr int kSegBytes = 128;  // run index of the first item of every 64-item segment of a tile (32 entries)
 
@@ -37,6 +34,7 @@ struct ExpandArgs {
   int32_t group_bytes;         // LDS of one group: segments | marks | pool (run slice, then packed bytes)
   uint8_t *values_out;
   TileDesc *descs;             // n_tiles entries, written by k_tile_desc
+  const int32_t *work_flag;    // not null: the launch has work only if this word is set (every stream may have been expanded already)
 };
 
 __host__ __device__ inline int runs_lds_bytes(int runs_cap) { return (runs_cap + 3) * (int)sizeof(RunEntry); }
@@ -89,6 +87,7 @@ __device__ __forceinline__ void decode4(const RunEntry *R, int nr, int v, int n4
 // k_tile_desc: one thread per tile, after the prescan: which runs, items and stream bytes the tile covers.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
+  if (a.work_flag && *a.work_flag == 0) return;
   const int tile = a.tile_lo + blockIdx.x * 256 + threadIdx.x;
   if (tile >= a.n_tiles) return;
   const ChunkCtx &c = a.c;
@@ -145,34 +144,6 @@ __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
   a.descs[tile] = d;
 }
 
-// One bit-packed group: W bytes at byte offset `rel` of the staging buffer -> eight values.
-// The bytes are fetched as aligned dwords, realigned by the byte offset, then every value sits at a
-// compile-time bit position.
-template <int W>
-__device__ __forceinline__ void unpack8(const uint32_t *s_stage, uint32_t rel, uint32_t x[8]) {
-  if (W == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = 0;
-    return;
-  }
-  constexpr int ND = W == 0 ? 1 : (W + 3) / 4;
-  constexpr uint32_t mask = W >= 32 ? 0xFFFFFFFFu : ((1u << (W & 31)) - 1u);
-  const uint32_t a = rel >> 2, sb = (rel & 3u) * 8u;
-  uint32_t raw[ND + 1];
-#pragma unroll
-  for (int i = 0; i <= ND; i++) raw[i] = s_stage[a + i];
-  uint32_t d[ND + 1];
-#pragma unroll
-  for (int i = 0; i < ND; i++) d[i] = __builtin_amdgcn_alignbit(raw[i + 1], raw[i], sb);
-  d[ND] = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int bit = j * W, lo = bit >> 5, sh = bit & 31;
-    if (sh + W <= 32) x[j] = (d[lo] >> sh) & mask;
-    else x[j] = __builtin_amdgcn_alignbit(d[lo + 1], d[lo], (uint32_t)sh) & mask;
-  }
-}
-
 // inclusive running maximum over the 64 lanes (DPP row shifts, then the two row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
   uint32_t y;
@@ -183,32 +154,6 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;  // row_bcast:15
   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;  // row_bcast:31
   return x;
-}
-
-// Stores values j0 .. j1-1 of an item (eight output elements starting at `outp`).
-__device__ __forceinline__ void store_item(uint32_t *outp, const uint32_t y[8], int j0, int j1) {
-  if (j0 == 0 && j1 == 8) {
-    U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}}, o1 = {{y[4], y[5], y[6], y[7]}};
-    reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0;
-    reinterpret_cast<U32x4Unaligned *>(outp)[1] = o1;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (j >= j0 && j < j1) outp[j] = y[j];
-  }
-}
-__device__ __forceinline__ void store_item(uint64_t *outp, const uint64_t y[8], int j0, int j1) {
-  if (j0 == 0 && j1 == 8) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      U64x2Unaligned o = {{y[2 * q], y[2 * q + 1]}};
-      reinterpret_cast<U64x2Unaligned *>(outp)[q] = o;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (j >= j0 && j < j1) outp[j] = y[j];
-  }
 }
 
 // DMODE 0: dictionary in global memory; 1: whole dictionary in LDS; 2: entries below dict_lds_n in LDS, the
@@ -544,6 +489,7 @@ __device__ __forceinline__ TileDesc ring_read(const uint32_t *slot) {
 template <int MODE, int DMODE, int G, int GT>
 __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const TileDesc *__restrict__ descs) {
   extern __shared__ uint4 smem[];
+  if (a.work_flag && *a.work_flag == 0) return;   // (uniform)
   uint8_t *lds = reinterpret_cast<uint8_t *>(smem);
   const int g = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
   const int gtid = G == 1 ? (int)threadIdx.x : (int)threadIdx.x % GT;
@@ -636,7 +582,7 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
   ExpandArgs a;
   a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 0; a.tile_lo = 0; a.n_tiles = n_tiles;
   a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.no_dict = 0; a.dict_lds_n = 0; a.dict_lds_bytes = 0;
-  a.values_out = nullptr; a.descs = descs;
+  a.values_out = nullptr; a.descs = descs; a.work_flag = nullptr;
   set_group_layout(a, kRunSlice, stage_bytes);
   int per_cu = kLdsTotal / (a.group_bytes + 512);
   if (per_cu > 8) per_cu = 8;
@@ -655,6 +601,7 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   a.no_dict = dict_n < 0;
   if (dict_n < 0) dict_n = 0;
   a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out; a.descs = descs;
+  a.work_flag = c.chunk_status + kWorkFlag;
   const int esz = c.elem_size;
   const size_t dict_bytes = ((size_t)dict_n * esz + 15) / 16 * 16;
   const bool fixed48 = esz == 4 || esz == 8;

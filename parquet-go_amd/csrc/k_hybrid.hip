@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64) void k_hybrid_prescan(ChunkCtx c, int s0) {
     if (lane == 0) { sp->n_runs = 0; sp->decoded = 0; }
     return;
   }
+  if (lane == 0) c.chunk_status[kWorkFlag] = 1;   // a stream for the tile expansion
   const int w = sp->w;
   const int64_t off = sp->off;
   const uint32_t L = (uint32_t)sp->len, avail = (uint32_t)sp->avail;
@@ -739,6 +740,8 @@ __global__ __launch_bounds__(1024) void k_pages_finalize(int n_blocks, int64_t *
     __syncthreads();   // s_wave and the read of s_tot[1] at the top of the next round
   }
   if (tid < 4) totals[tid] = (int64_t)s_tot[tid];
+  // the mark the run-header walks leave when a stream needs the tile expansion (chunk_status[kWorkFlag]) starts clear
+  if (tid == 0) reinterpret_cast<int32_t *>(totals)[kStatusWord + kWorkFlag] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c, const int64_t *__restrict__ block_sums) {

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void k_hybrid_prescan_wide(ChunkCtx c, in
     if (tid == 0) { sp->n_runs = 0; sp->decoded = 0; }
     return;
   }
+  if (tid == 0) c.chunk_status[kWorkFlag] = 1;   // a stream for the tile expansion
   const int w = sp->w;
   if (w > 32) {
     if (tid == 0) { sp->status = PQD_ERR_BIT_WIDTH; sp->n_runs = 0; }

@@ -112,7 +112,7 @@ struct KernelEvent {
 };
 
 // Process-wide defaults of the per-handle options, read from the environment once (PQD_PRESCAN=wide|wave,
-// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_HEAVY_LANES=0..4).
+// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_FUSED=0|1, PQD_HEAVY_LANES=0..4).
 struct Defaults {
   int opt[PQD_OPT_COUNT];
   int heavy_lanes;
@@ -130,6 +130,7 @@ const Defaults &defaults() {
     if (const char *e = std::getenv("PQD_SPLIT")) x.opt[PQD_OPT_SPLIT] = e[0] == '1';
     if (const char *e = std::getenv("PQD_POISON")) x.opt[PQD_OPT_POISON] = e[0] == '1';
     if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_FUSED")) x.opt[PQD_OPT_FUSED] = e[0] == '1';
     const char *e = std::getenv("PQD_HEAVY_LANES");
     const int v = e ? std::atoi(e) : 0;
     x.heavy_lanes = v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
@@ -269,7 +270,7 @@ hipStream_t heavy_stream(int device) {
 bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY; }
 
 // layout of the 256-byte block every call copies back: totals | status | byte total
-constexpr int kSmallStatus = 16;       // int32 index: [16] status, [17] bad page
+constexpr int kSmallStatus = kStatusWord;  // int32 index: [16] status, [17] bad page, [20] work flag
 constexpr int kSmallByteTotal = 16;    // int64 index: byte total of a BYTE_ARRAY call
 
 // The byte copies of a BYTE_ARRAY call, against the current capacity of h->bytes.
@@ -583,6 +584,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first
   bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;
   if (h->opt[PQD_OPT_DIRECT_RLE] >= 0) direct_rle = h->opt[PQD_OPT_DIRECT_RLE] == 1;
+  // large pages: the index stream of a page walked and expanded by one workgroup, in one pass over its bytes
+  constexpr int kFusedMinLen = 16 * 1024;
+  bool fused = nd > 0 && data_bytes / nd >= 2 * kFusedMinLen;
+  if (h->opt[PQD_OPT_FUSED] >= 0) fused = h->opt[PQD_OPT_FUSED] == 1;
+  int max_dict_n = 0;
+  for (int p = 0; p < n_pages; p++)
+    if (h->h_pages[(size_t)p].data_idx < 0) max_dict_n = std::max(max_dict_n, h->h_pages[(size_t)p].dict_n);
 
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
@@ -694,6 +702,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (n_dict) { Prof pf(h, "k_dict_plain_fixed"); HIP_TRY(launch_dict_plain_fixed(c, d_dictp, n_dict, static_cast<uint8_t *>(h->dict.p), h->stream)); }
     if (any_dict_enc || any_rle) {
       if (direct_rle && any_dict_enc && (esz == 4 || esz == 8)) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c, static_cast<const uint8_t *>(h->dict.p), dense_out, h->stream)); }
+      if (fused && any_dict_enc && (esz == 4 || esz == 8)) { Prof pf(h, "k_page_fused");
+        HIP_TRY(launch_page_fused(c, static_cast<const uint8_t *>(h->dict.p), dense_out, max_dict_n, h->opt[PQD_OPT_FUSED] == 1 ? 1 : kFusedMinLen, h->stream)); }
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);

@@ -8,6 +8,10 @@ namespace pqd {
 constexpr int kTile = 4096;        // values per expand tile (256 threads x 16 values)
 constexpr int kRunSlice = 1024;    // run-table entries of one tile kept in LDS
 constexpr int kPlainTile = 16384;  // bytes per block-iteration of the flat copy kernels
+// ChunkCtx::chunk_status[kWorkFlag]: set by the run-header walk of the dictionary-index streams when a stream is left for
+// the tile expansion (cleared by k_pages_finalize before); while it is clear the expansion kernels return at once
+constexpr int kWorkFlag = 4;
+constexpr int kStatusWord = 16;     // chunk_status sits this many 32-bit words into the handle's block of totals
 
 // One page as the host describes it (built from pqd_page_desc).
 struct PageIn {

@@ -18,6 +18,11 @@ hipError_t launch_hybrid_prescan(const ChunkCtx &c, int s0, int n, bool wide, bo
 hipError_t launch_rle_only_pages(const ChunkCtx &c, const uint8_t *dict_table, uint8_t *values_out, hipStream_t stream);
 // the same for the repetition / definition level streams (streams [0, 2 nd)); counts nulls and row starts per page
 hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *def_out, hipStream_t stream);
+// Dictionary-index streams of large pages (at least min_len bytes, 4- or 8-byte entries): run headers walked and values
+// written by one workgroup per page, the page read once; streams it finishes are marked and skipped by the prescan and
+// the tile expansion, anything unusual is left to them.  max_dict_n: entries of the largest dictionary of the call.
+hipError_t launch_page_fused(const ChunkCtx &c, const uint8_t *dict_table, uint8_t *values_out, int max_dict_n, int min_len,
+                             hipStream_t stream);
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)

@@ -54,12 +54,14 @@ def test_dictionary_chunk_equals_its_halves_and_the_oracle(pq, oracle):
     r = dec.wait(check=True)
     assert r.num_slots == n and r.num_rows == n and r.num_nulls == 0
     full = dev_tensor(dec.device_result().values, n, "<i4").clone()
+    torch.cuda.synchronize()   # the copy runs on torch's stream: it must be done before the handle's buffer is written again
     half = 1 + (pages.size - 1) // 2
     parts = []
     for sub in (pages[:half], np.concatenate([pages[:1], pages[half:]])):
         dec.submit_device(dev.data_ptr(), chunk.size, sub, pq.INT32)
         r2 = dec.wait(check=True)
         parts.append(dev_tensor(dec.device_result().values, r2.num_slots, "<i4").clone())
+        torch.cuda.synchronize()
     assert parts[0].numel() + parts[1].numel() == n
     assert torch.equal(full, torch.cat(parts))
     assert checksum(full) == checksum(torch.cat(parts))
@@ -105,6 +107,7 @@ def test_two_encodings_of_the_same_strings_decode_alike(pq, oracle):
         assert r.num_slots == n
         d = dec.device_result()
         out[mode] = (dev_tensor(d.offsets, n + 1, "<i8").clone(), dev_tensor(d.bytes, r.bytes_len, "|u1").clone())
+        torch.cuda.synchronize()   # the copies run on torch's stream: done before the handle's buffers are written again
         if mode == 1:
             o = oracle.read_chunk(chunk, pages[:1], oracle.BYTE_ARRAY)
             assert o.status == 0
