@@ -277,6 +277,11 @@ int pqd_row_starts(pqd_handle *h, int64_t *host_out, int64_t cap, int64_t **devi
  * (dictionary pages report zeros). */
 int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages);
 
+/* How many data pages of the last decode call (after pqd_wait) had their dictionary-index stream expanded straight from
+ * the page, by the RLE-only kernel or the one-pass kernel, instead of through a run table.  A diagnostic: results do
+ * not depend on it.  No counterpart in the reference (its decoders have one path, encoding/encodingread.go:230-268). */
+int pqd_direct_streams(pqd_handle *h, int32_t *n_out);
+
 /* Per-kernel timings of the last decode call (pqd_set_profiling(h, 1) first). */
 int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out);
 

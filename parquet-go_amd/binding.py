@@ -26,10 +26,10 @@ EXPORTS = [
     "pqd_input_buffer", "pqd_set_option", "pqd_decode_chunks", "pqd_decode_chunks_device",
     "pqd_footer_locate", "pqd_footer_parse", "pqd_footer_free", "pqd_footer_num_rows", "pqd_footer_num_row_groups",
     "pqd_footer_num_leaves", "pqd_footer_num_chunks", "pqd_footer_leaf", "pqd_footer_chunk",
-    "pqd_decode_chunk_device_noalloc",
+    "pqd_decode_chunk_device_noalloc", "pqd_direct_streams",
 ]
 
-OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON, OPT_DELTA_BLOCKS = range(7)
+OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON, OPT_DELTA_BLOCKS, OPT_FUSED = range(8)
 LEVELS_ONLY = 1
 ERR_CAPACITY = -14
 
@@ -92,6 +92,7 @@ def lib():
         L.pqd_handle_destroy.argtypes = [C.c_void_p]
         L.pqd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pqd_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.pqd_direct_streams.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         for fn in (L.pqd_decode_chunks, L.pqd_decode_chunks_device):
             fn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_ColDesc), C.c_int32]
         L.pqd_scan_pages.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -303,6 +304,12 @@ class Decoder:
         out = np.zeros(r.num_rows + 1, np.int64)
         _check(lib().pqd_row_starts(self._h, C.c_void_p(out.ctypes.data), out.size, None))
         return out
+
+    def direct_streams(self):
+        """Data pages of the last call whose index stream was expanded straight from the page (a diagnostic)."""
+        n = C.c_int32(0)
+        _check(lib().pqd_direct_streams(self._h, C.byref(n)))
+        return n.value
 
     def kernel_times(self):
         arr = (_KernelTime * 32)()

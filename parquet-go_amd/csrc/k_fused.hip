@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "pqd_kernels.h"
 #include "pqd_device.h"
+#include <cstdlib>
 
 namespace pqd {
 
@@ -384,8 +385,16 @@ static hipError_t launch_fused_t(const ChunkCtx &c, const uint8_t *dict_table, u
     // larger dictionaries: one workgroup of sixteen wavefronts per CU, all the LDS the ring leaves holds the head of the
     // dictionary (a random 4-byte gather from L2 is bound by its request rate: every entry that sits in LDS counts)
     size_t room = (size_t)(kLdsPerCu - kFusedFixedLds - 512) / 16 * 16;
+    static const int head_kib = std::getenv("PQD_FUSED_HEAD") ? std::atoi(std::getenv("PQD_FUSED_HEAD")) : -1;
+    if (head_kib >= 0 && (size_t)head_kib * 1024 < room) room = (size_t)head_kib * 1024;
     if (room > dict_bytes) room = dict_bytes;
     const size_t shmem = room + kFusedFixedLds;
+    if (head_kib >= 0 && head_kib <= 40) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_page_fused<T, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_page_fused<T, 2, 8>), dim3(c.nd), dim3(512), shmem, stream, c, dt, vo, (int)room, min_len);
+      return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_page_fused<T, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_page_fused<T, 2, 16>), dim3(c.nd), dim3(1024), shmem, stream, c, dt, vo, (int)room, min_len);

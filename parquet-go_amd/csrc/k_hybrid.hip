@@ -1013,20 +1013,25 @@ hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *
 // k_collect_status: first failing page of the chunk, in page order (the reference stops at the first
 // page whose ReadPage returns an error).  out[0] = status, out[1] = page index or -1.
 // ---------------------------------------------------------------------------------------------
+// out[kDirectCount]: data pages whose index stream was expanded straight from the page (k_rle_only_pages, k_page_fused).
 __global__ __launch_bounds__(1024) void k_collect_status(ChunkCtx c, int32_t *out) {
-  __shared__ int s_first;
-  if (threadIdx.x == 0) s_first = 0x7FFFFFFF;
+  __shared__ int s_first, s_direct;
+  if (threadIdx.x == 0) { s_first = 0x7FFFFFFF; s_direct = 0; }
   __syncthreads();
+  int n_direct = 0;
   for (int p = threadIdx.x; p < c.n_pages; p += 1024) {
     int st = c.state[p].status;
     const int d = c.pages[p].data_idx;
+    if (d >= 0) n_direct += c.streams[2 * c.nd + d].direct != 0;
     if (st == 0 && d >= 0) st = c.streams[2 * c.nd + d].status;
     if (st != 0) { atomicMin(&s_first, p); c.state[p].status = st; }
   }
+  if (n_direct) atomicAdd(&s_direct, n_direct);
   __syncthreads();
   if (threadIdx.x == 0) {
     if (s_first == 0x7FFFFFFF) { out[0] = 0; out[1] = -1; }
     else { out[0] = c.state[s_first].status; out[1] = s_first; }
+    out[kDirectCount] = s_direct;
   }
 }
 
@@ -1053,6 +1058,7 @@ __global__ __launch_bounds__(256) void k_collect_status_wide(ChunkCtx c, int32_t
   if (p >= c.n_pages) return;
   int st = c.state[p].status;
   const int d = c.pages[p].data_idx;
+  if (d >= 0 && c.streams[2 * c.nd + d].direct != 0) atomicAdd(&out[kDirectCount], 1);
   if (st == 0 && d >= 0) st = c.streams[2 * c.nd + d].status;
   if (st != 0) { atomicMin(&out[1], p); c.state[p].status = st; }
 }
@@ -1066,6 +1072,8 @@ hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t st
     hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(1024), 0, stream, c, out);
   } else {
     hipError_t e = hipMemsetAsync(out + 1, 0x7F, 4, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(out + kDirectCount, 0, 4, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_collect_status_wide, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c, out);
     hipLaunchKernelGGL(k_collect_status_done, dim3(1), dim3(1), 0, stream, c, out);

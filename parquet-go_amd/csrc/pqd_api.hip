@@ -1213,6 +1213,13 @@ int pqd_page_counts(pqd_handle *h, int64_t *out, int32_t cap_pages) {
   )
 }
 
+int pqd_direct_streams(pqd_handle *h, int32_t *n_out) {
+  if (!h || !n_out) return fail_arg("NULL argument");
+  if (!h->have_result) return fail_arg("no completed decode call");
+  *n_out = (static_cast<const int32_t *>(h->host_small.p) + kSmallStatus)[kDirectCount];
+  return PQD_OK;
+}
+
 int pqd_kernel_times(pqd_handle *h, pqd_kernel_time *out, int32_t cap, int32_t *n_out) {
   if (!h || !n_out) return fail_arg("NULL argument");
   Guard g(h->device);

@@ -11,6 +11,7 @@ constexpr int kPlainTile = 16384;  // bytes per block-iteration of the flat copy
 // ChunkCtx::chunk_status[kWorkFlag]: set by the run-header walk of the dictionary-index streams when a stream is left for
 // the tile expansion (cleared by k_pages_finalize before); while it is clear the expansion kernels return at once
 constexpr int kWorkFlag = 4;
+constexpr int kDirectCount = 5;    // chunk_status[kDirectCount]: index streams expanded straight from their pages (k_collect_status)
 constexpr int kStatusWord = 16;     // chunk_status sits this many 32-bit words into the handle's block of totals
 
 // One page as the host describes it (built from pqd_page_desc).

@@ -23,7 +23,7 @@ def dec(shared_dec):
     # one handle for the module (its work buffers are reused from test to test, as a reader reuses them from chunk
     # to chunk); kernel-variant choices a test pins are handed back to the library afterwards
     yield shared_dec
-    for opt in range(7):
+    for opt in range(8):
         shared_dec.set_option(opt, -1)
 
 
@@ -209,6 +209,128 @@ def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, d
             g, o = check_same(dec, oracle, chunk, pages, ptype, 0, max_def[0], max_def[1])
             if hi and nd < (1 << (8 * nb)):
                 assert o.status == oracle.PANIC and o.bad_page == 3
+
+
+def _runs_body(rng, w, nd, n_target, mix):
+    """Index stream of runs drawn from `mix` (kind -> weight) until it holds n_target values; returns (bytes, values)."""
+    nb = (w + 7) // 8
+    kinds = list(mix)
+    p = np.array([mix[k] for k in kinds], float)
+    p /= p.sum()
+    out, vals = bytearray(), []
+
+    def rle(c):
+        v = int(rng.integers(0, nd))
+        out.extend(pg.varint(c << 1) + v.to_bytes(4, "little")[:nb])
+        vals.extend([v] * c)
+
+    def bp(g):
+        x = rng.integers(0, nd, 8 * g)
+        out.extend(pg.varint((g << 1) | 1) + pg.bitpack(x, w))
+        vals.extend(x.tolist())
+
+    while len(vals) < n_target:
+        k = kinds[int(rng.choice(len(kinds), p=p))]
+        if k == "bp":            # one-byte header, up to 63 groups
+            bp(int(rng.integers(1, 64)))
+        elif k == "bp2":         # two-byte header: a payload of many KiB, crossing several windows of the walk
+            bp(int(rng.integers(64, min(8192, 64 + 40000 // max(w, 1)))))
+        elif k == "rle":
+            rle(int(rng.integers(1, 64)))
+        elif k == "rle2":        # two-byte header
+            rle(int(rng.integers(64, 8192)))
+        elif k == "short":       # a few values per run: more runs in a window than one step of the walk takes
+            if rng.integers(0, 2):
+                rle(int(rng.integers(1, 4)))
+            else:
+                bp(1)
+        elif k == "rle3":        # three-byte header
+            rle(int(rng.integers(8192, 9000)))
+        elif k == "empty":
+            out.extend(b"\x00" + bytes(nb))
+        elif k == "emptybp":
+            out.extend(b"\x01")
+    return bytes(out), vals
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("ptype,w,nd", [(pg.INT32, 1, 2), (pg.INT32, 3, 7), (pg.INT32, 8, 256), (pg.INT32, 12, 4096), (pg.INT64, 12, 3000),
+                                        (pg.DOUBLE, 5, 32), (pg.INT32, 16, 65536), (pg.INT32, 20, 65536), (pg.INT64, 15, 30000),
+                                        (pg.INT32, 32, 5000), (pg.FLOAT, 17, 20000)])
+def test_large_pages_walked_and_expanded_in_one_pass(dec, oracle, ptype, w, nd, fused):
+    # Index streams of pages large enough for the one-pass kernel (a workgroup per page: a wavefront follows the run
+    # headers through a ring of page bytes in LDS, the others expand out of it): pages of many windows, runs with one-
+    # and two-byte headers, bit-packed runs that span several windows, stretches of more runs per window than one step
+    # takes, a count that ends inside the last run, two dictionaries in one chunk, a nullable column; and the pages
+    # the kernel must leave to the general path - a three-byte header, empty runs, bytes behind the last run, too few
+    # values - each behind good pages; an index beyond the dictionary.  Same results with the kernel on and off.
+    dec.set_option(7, int(fused))            # PQD_OPT_FUSED
+    rng = np.random.default_rng(7700 + w + ptype)
+    common = {"bp": 60, "rle": 20, "rle2": 5, "bp2": 3}
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 9)), lead=int(rng.integers(0, 5)))
+    cb.dict_page(rand_dict(rng, ptype, nd), nd)
+    nvals = (120000, 40000, 9000, 200) if w < 16 else (60000, 20000, 300)
+    for k, n_target in enumerate(nvals):
+        body, vals = _runs_body(rng, w, nd, n_target, common if k != 1 else {"bp": 30, "rle": 10, "short": 60})
+        n = len(vals) - int(rng.integers(0, min(8, len(vals))))      # the count may end inside the last run
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([w]) + body)
+    # a second, smaller dictionary for the pages behind it
+    nd2 = max(1, nd // 3)
+    cb.dict_page(rand_dict(rng, ptype, nd2), nd2)
+    body, vals = _runs_body(rng, w, nd2, 30000, common)
+    cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, len(vals), bytes([w]) + body)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype)
+    assert o.status == 0
+    # with the kernel on, every index stream of this chunk was finished by it (none fell back to the general path)
+    dec.decode(chunk, pages, ptype)
+    assert dec.direct_streams() == (len(nvals) + 1 if fused == "1" else 0)
+    # nullable and nested: the values of a page are fewer than its slots and land behind those of the pages before it
+    cb = pg.ChunkBuilder(gap=2)
+    cb.dict_page(rand_dict(rng, ptype, nd), nd)
+    for n in (50000, 30000):
+        dl, rl = _levels(rng, n, 2, 1)
+        nn = int((dl == 2).sum())
+        body, vals = _runs_body(rng, w, nd, nn, common)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([w]) + body, pg.level_block_v1(rl, 1, rng, "mixed"), pg.level_block_v1(dl, 2, rng, "mixed"))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype, 0, 2, 1)
+    assert o.status == 0
+    # pages for the general path, each behind a good page
+    nb = (w + 7) // 8
+    for what in ("rle3", "empty", "emptybp", "tail", "short", "index"):
+        cb = pg.ChunkBuilder(gap=1)
+        cb.dict_page(rand_dict(rng, ptype, nd), nd)
+        body, vals = _runs_body(rng, w, nd, 30000, common)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, len(vals), bytes([w]) + body)
+        body, vals = _runs_body(rng, w, nd, 20000, common)
+        if what in ("rle3", "empty", "emptybp"):
+            if what == "rle3":
+                odd, odd_vals = _runs_body(rng, w, nd, 1, {what: 1})
+            else:
+                odd, odd_vals = (b"\x00" + bytes(nb) if what == "empty" else b"\x01"), []
+            more, more_vals = _runs_body(rng, w, nd, 20000, common)
+            body, vals = body + odd + more, vals + odd_vals + more_vals
+        n = len(vals)
+        if what == "tail":
+            body += b"\x02" + bytes(nb)          # a run behind the one that completes the count
+        elif what == "short":
+            n += 5                               # the stream holds too few values
+        elif what == "index":
+            if nd >= (1 << min(w, 31)):
+                continue
+            v = (1 << w) - 1
+            body += pg.varint(9 << 1) + v.to_bytes(4, "little")[:nb]   # dict.Values[index] out of range
+            n += 9
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([w]) + body)
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, ptype)
+        if what in ("short", "index"):
+            assert o.status != 0 and o.bad_page == 2
+        # the good page is finished by the kernel, the odd one is left to the general path (an index beyond the dictionary
+        # is no concern of the walk: that page is finished too, and fails as the reference's gather does)
+        dec.decode(chunk, pages, ptype)
+        assert dec.direct_streams() == ((2 if what == "index" else 1) if fused == "1" else 0), what
 
 
 @pytest.mark.parametrize("variant", ["wave", "wide"])
