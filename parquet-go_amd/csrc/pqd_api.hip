@@ -662,6 +662,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (n_dict) { Prof pf(h, "k_plain_ba_walk(dict)"); HIP_TRY(launch_plain_ba_walk(c, d_dictp, n_dict, static_cast<uint64_t *>(h->dict_pairs.p), h->stream)); }
     if (any_dict_enc) {
       if (direct_rle) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c8, static_cast<const uint8_t *>(h->dict_pairs.p), reinterpret_cast<uint8_t *>(pairs), h->stream)); }
+      if (fused) { Prof pf(h, "k_page_fused");   // (the dictionary entries are the 8-byte descriptors of the strings)
+        HIP_TRY(launch_page_fused(c8, static_cast<const uint8_t *>(h->dict_pairs.p), reinterpret_cast<uint8_t *>(pairs), max_dict_n,
+                                  h->opt[PQD_OPT_FUSED] == 1 ? 1 : kFusedMinLen, h->stream)); }
       { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);

@@ -968,6 +968,35 @@ def test_byte_array_dictionary(dec, oracle):
     assert g.bytes.tobytes() == b"StudentName" * 100
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_byte_array_dictionary_large_pages(dec, oracle, fused):
+    # dictionary-encoded strings in pages large enough for the one-pass kernel: the dictionary entries it looks up are
+    # the descriptors of the strings; with nulls; same result with the kernel on and off
+    dec.set_option(7, int(fused))            # PQD_OPT_FUSED
+    rng = np.random.default_rng(6100)
+    words = rand_strings(rng, 900, 0, 24)
+    mix = {"bp": 60, "rle": 20, "rle2": 5, "bp2": 3}
+    cb = pg.ChunkBuilder(gap=5)
+    cb.dict_page(pg.plain_byte_array(words), len(words))
+    for n_target in (50000, 20000, 100):
+        body, vals = _runs_body(rng, 10, len(words), n_target, mix)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, len(vals) - 3, bytes([10]) + body)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+    assert o.status == 0
+    dec.decode(chunk, pages, pg.BYTE_ARRAY)
+    assert dec.direct_streams() == (3 if fused == "1" else 0)
+    cb = pg.ChunkBuilder(gap=1)
+    cb.dict_page(pg.plain_byte_array(words), len(words))
+    for n in (40000, 9000):
+        dl, rl = _levels(rng, n, 1, 0)
+        body, vals = _runs_body(rng, 10, len(words), int((dl == 1).sum()), mix)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, bytes([10]) + body, b"", pg.level_block_v1(dl, 1, rng, "mixed"))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY, 0, 1, 0)
+    assert o.status == 0
+
+
 def test_byte_array_dictionary_page_announcing_more_entries_than_it_holds(dec, oracle):
     # the dictionary page fails part way through (encodingread.go:98-125: EOF at the entry after the last one), the
     # data pages are expanded all the same and use indices of entries that were never read: those must read as
