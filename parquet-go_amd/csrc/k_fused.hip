@@ -5,20 +5,22 @@
 // header before it), so a page is walked by one wavefront whatever else happens.  Run tables written by one kernel and
 // expanded by another make every page byte cross the memory bus twice and put the two serial steps of a chunk one
 // behind the other; here a workgroup owns a page: wavefront 0 follows the chain through a ring of stream bytes in LDS
-// and leaves, per window of the ring, a short list of runs; the other wavefronts turn the list of the window before
-// into values (unpack, dictionary lookup, stores) out of the same ring.  One barrier per window.
+// and leaves, per step (a window of the ring, or kFRunCap runs of it), a short list of runs; the other wavefronts turn
+// the list of the step before into values (unpack, dictionary lookup, stores) out of the same ring.  One barrier per
+// step.  What bounds it: alone on the GPU a page takes as long as its walk (about 75 ns a run); with two or three
+// pages per CU in flight - several chunks decoded side by side, or a call of many pages - the memory system
+// (about 4.6 TB/s of page bytes read and values written).
 //
 // Only clean streams are finished here: headers of one or two bytes, no empty runs, every run inside the stream, the
-// stream ending with the run that completes the page's count.  Anything else - and any window with more runs than
-// the list holds - leaves the stream to the general path (k_hybrid_prescan + k_hybrid_expand), which writes the same
-// places again, so the reference's behaviour on odd input stays in one place.
+// stream ending with the run that completes the page's count.  Anything else leaves the stream to the general path
+// (k_hybrid_prescan + k_hybrid_expand), which writes the same places again, so the reference's behaviour on odd input
+// stays in one place.
 //
 // Reference behaviour reproduced: encoding/encodingread.go:127-268 (varint, RLE run, bit-packed run, hybrid),
 // layout/page.go:644-655 (index stream of a dictionary-encoded page), :139-164 (dictionary gather).
 #include <hip/hip_runtime.h>
 #include "pqd_kernels.h"
 #include "pqd_device.h"
-#include <cstdlib>
 
 namespace pqd {
 
@@ -26,7 +28,7 @@ constexpr int kFWin = 8192;                 // bytes per ring slot (one window o
 constexpr int kFSlots = 4;
 constexpr int kFRing = kFWin * kFSlots;
 constexpr int kFMirror = 64;                // the ring's first bytes once more behind its end: reads run on across the wrap
-constexpr int kFRunCap = 128;               // runs per step of the walk (a window of more takes several steps)
+constexpr int kFRunCap = 64;                // runs per step of the walk (a window of more takes several steps)
 constexpr uint32_t kFBp = 0x80000000u;
 
 // One run, or the part of a bit-packed run whose groups start inside the window.
@@ -85,22 +87,65 @@ __device__ __forceinline__ void fused_lookup8(const T *s_dict, const T *dict, ui
   for (int j = 0; j < 8; j++) y[j] = x[j] < dict_lds_n ? yl[j] : yg[j];
 }
 
-// The items of one list: wavefront `ew` of `ne` takes 64 consecutive items per step; the entry holding an item is
-// found by bisection over the item counts (a uniform number of steps).
+// Stores the first j1 values of an item (eight output elements starting at `outp`); a short item - the end of an RLE
+// run or of the page - as one vector and up to three single elements.
+__device__ __forceinline__ void fused_store(uint32_t *outp, const uint32_t y[8], uint32_t j1) {
+  if (j1 == 8u) {
+    U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}}, o1 = {{y[4], y[5], y[6], y[7]}};
+    reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0;
+    reinterpret_cast<U32x4Unaligned *>(outp)[1] = o1;
+  } else if (j1 != 0u) {
+    // (only an RLE item is ever short of eight, or the page's last item: all its values are y[0] in the first case)
+    uint32_t k = 0;
+    if (j1 >= 4u) { U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}}; reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0; k = 4; }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((uint32_t)j >= k && (uint32_t)j < j1) outp[j] = y[j];
+  }
+}
+__device__ __forceinline__ void fused_store(uint64_t *outp, const uint64_t y[8], uint32_t j1) {
+  if (j1 == 8u) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      U64x2Unaligned o = {{y[2 * q], y[2 * q + 1]}};
+      reinterpret_cast<U64x2Unaligned *>(outp)[q] = o;
+    }
+  } else if (j1 != 0u) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((uint32_t)j < j1) outp[j] = y[j];
+  }
+}
+
+// The items of one list: wavefront `ew` of `ne` takes 64 consecutive items per step.  The entry holding an item: every
+// lane keeps the item count of one entry (two, for a long list), so the entries of the step's first and last item
+// come from two ballots, and the lanes in between step through the few entries that separate them.
 template <class T, int DMODE, int W>
 __device__ __forceinline__ void fused_expand(const FusedList *L, const uint32_t *ring32, const T *s_dict, const T *dict,
                                              uint32_t dict_n, uint32_t dict_lds_n, T *out, uint32_t ucnt, int ew, int ne, int lane,
                                              bool &bad_index) {
   const uint32_t n = rfl(L->n), total = rfl(L->items);
   const bool check_bp = !(W < 32 && (1u << (W & 31)) <= dict_n);   // can a packed index be out of range
+  if ((uint32_t)ew * 64u >= total) return;
+  const uint32_t z0 = (uint32_t)lane < n ? L->e[lane].item0 : 0xFFFFFFFFu;
+  const uint32_t z1 = (uint32_t)lane + 64u < n ? L->e[lane + 64].item0 : 0xFFFFFFFFu;
+  const uint32_t z2 = (uint32_t)lane + 128u < n ? L->e[lane + 128].item0 : 0xFFFFFFFFu;   // (a list holds up to kFRunCap + 1 entries)
+  static_assert(kFRunCap + 2 <= 192, "three entries per lane cover a list");
+  auto z_of = [&](uint32_t d) -> uint32_t {
+    return d < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)z0, (int)d)
+                   : d < 128u ? (uint32_t)__builtin_amdgcn_readlane((int)z1, (int)d - 64) : (uint32_t)__builtin_amdgcn_readlane((int)z2, (int)d - 128);
+  };
+  auto last_le = [&](uint32_t it) -> uint32_t {     // the last entry whose items start at or before `it` (uniform)
+    return (uint32_t)(__builtin_popcountll(__ballot(z0 <= it)) + __builtin_popcountll(__ballot(z1 <= it)) +
+                      __builtin_popcountll(__ballot(z2 <= it))) - 1u;
+  };
   for (uint32_t it0 = (uint32_t)ew * 64u; it0 < total; it0 += (uint32_t)ne * 64u) {
     const uint32_t it = it0 + (uint32_t)lane;
-    uint32_t lo = 0, len = n;
-    while (len > 1) {
-      const uint32_t half = len >> 1;
-      if (L->e[lo + half].item0 <= it) lo += half;
-      len -= half;
-    }
+    const uint32_t it_hi = it0 + 63u < total ? it0 + 63u : total - 1u;
+    const uint32_t lo_u = last_le(it0), hi_u = last_le(it_hi);
+    uint32_t lo = lo_u;
+    for (uint32_t d = lo_u + 1u; d <= hi_u; d++)
+      if (z_of(d) <= it) lo = d;
     if (it < total) {
       const FusedEntry e = L->e[lo];
       const uint32_t k = it - e.item0, nv = e.nv & 0x7FFFFFFFu;
@@ -110,20 +155,19 @@ __device__ __forceinline__ void fused_expand(const FusedList *L, const uint32_t 
       if (o >= ucnt) j1 = 0;                       // values beyond the page's count are read by the reference and dropped
       else if (ucnt - o < j1) j1 = ucnt - o;
       uint32_t x[8];
-      if (bp) {
-        unpack8<W>(ring32, (e.y + k * (uint32_t)W) & (uint32_t)(kFRing - 1), x);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = e.y;
-      }
-      if (bp ? check_bp : true) {
+      unpack8<W>(ring32, bp ? (e.y + k * (uint32_t)W) & (uint32_t)(kFRing - 1) : 0u, x);
+      if (check_bp) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
-          if (x[j] >= dict_n) { bad_index = bad_index || (uint32_t)j < j1; x[j] = 0; }   // dict.Values[index] out of range
+          if (x[j] >= dict_n) { bad_index = bad_index || (bp && (uint32_t)j < j1); x[j] = 0; }   // dict.Values[index] out of range
       }
+      uint32_t ry = e.y;
+      if (!bp && ry >= dict_n) { bad_index = bad_index || j1 != 0u; ry = 0; }
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = bp ? x[j] : ry;
       T y[8];
       fused_lookup8<T, DMODE>(s_dict, dict, dict_lds_n, x, y);
-      store_item(out + o, y, 0, (int)j1);
+      fused_store(out + o, y, j1);
     }
   }
 }
@@ -205,21 +249,23 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
   auto walk = [&](FusedList *L) {
     const uint32_t E = (R + 1u) * (uint32_t)kFWin;
     const uint32_t whi = E < qend ? E : qend;
+    // Window R + 2 comes in while window R is walked: loads that write LDS themselves (no registers held across the
+    // walk; a wavefront-instruction fills 64 x 16 consecutive bytes), waited for at the step's barrier.
     constexpr int NV = kFWin / 16 / 64;
-    uint4 v[NV];
-    int lmode = 0;
+    typedef __attribute__((address_space(3))) uint32_t *LdsDst;
+    typedef const __attribute__((address_space(1))) uint32_t *GlobalSrc;
     const uint32_t jl = R + 2u;
     if (first && jl * (uint32_t)kFWin < qend + 48u) {
       const uint8_t *p = base16 + (size_t)jl * kFWin + 16 * lane;
-      if (base16 + (size_t)(jl + 1u) * kFWin <= in_end) {
-        lmode = 1;
+      const uint32_t slot = jl & (uint32_t)(kFSlots - 1);
+      uint8_t *dst = reinterpret_cast<uint8_t *>(ring32) + slot * (uint32_t)kFWin;
+      const bool whole = base16 + (size_t)(jl + 1u) * kFWin <= in_end;
 #pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = *reinterpret_cast<const uint4 *>(p + 1024 * k);
-      } else {
-        lmode = 2;
-#pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = load_vec(jl, lane + 64 * k);
-      }
+      for (int k = 0; k < NV; k++)
+        if (whole || p + 1024 * k < in_end)    // (the granule of a lane that loads holds bytes of the buffer)
+          __builtin_amdgcn_global_load_lds((GlobalSrc)(p + 1024 * k), (LdsDst)(dst + 1024 * k), 16, 0, 0);
+      if (slot == 0 && lane < kFMirror / 16 && (whole || p < in_end))
+        __builtin_amdgcn_global_load_lds((GlobalSrc)p, (LdsDst)(reinterpret_cast<uint8_t *>(ring32) + kFRing), 16, 0, 0);
     }
     uint32_t n_list = 0, items = 0;
     if (cg) {
@@ -318,20 +364,13 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
       }
     }
     if (!fin && !bail && cg == 0 && q >= qend) bail = true;   // the stream holds too few values
-    if (lmode == 1) {
-      const uint32_t slot = jl & (uint32_t)(kFSlots - 1);
-#pragma unroll
-      for (int k = 0; k < NV; k++) ring4[slot * (kFWin / 16) + lane + 64 * k] = v[k];
-      if (slot == 0 && lane < kFMirror / 16) ring4[kFRing / 16 + lane] = v[0];
-    } else if (lmode == 2) {
-#pragma unroll
-      for (int k = 0; k < NV; k++) put_vec(jl, lane + 64 * k, v[k]);
-    }
     if (lane == 0) { L->n = n_list; L->items = items; L->flags = ((fin && cg == 0) ? 1u : 0u) | (bail ? 2u : 0u); }
     first = cg != 0 || q >= whi;
     if (first) R++;
   };
 
+  // the walk is the one serial chain of the page: its wavefront goes first whenever it has an instruction ready
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);
   if (wave == 0) walk(&lists[0]);
   __syncthreads();
 
@@ -385,16 +424,8 @@ static hipError_t launch_fused_t(const ChunkCtx &c, const uint8_t *dict_table, u
     // larger dictionaries: one workgroup of sixteen wavefronts per CU, all the LDS the ring leaves holds the head of the
     // dictionary (a random 4-byte gather from L2 is bound by its request rate: every entry that sits in LDS counts)
     size_t room = (size_t)(kLdsPerCu - kFusedFixedLds - 512) / 16 * 16;
-    static const int head_kib = std::getenv("PQD_FUSED_HEAD") ? std::atoi(std::getenv("PQD_FUSED_HEAD")) : -1;
-    if (head_kib >= 0 && (size_t)head_kib * 1024 < room) room = (size_t)head_kib * 1024;
     if (room > dict_bytes) room = dict_bytes;
     const size_t shmem = room + kFusedFixedLds;
-    if (head_kib >= 0 && head_kib <= 40) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_page_fused<T, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((k_page_fused<T, 2, 8>), dim3(c.nd), dim3(512), shmem, stream, c, dt, vo, (int)room, min_len);
-      return hipGetLastError();
-    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_page_fused<T, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_page_fused<T, 2, 16>), dim3(c.nd), dim3(1024), shmem, stream, c, dt, vo, (int)room, min_len);

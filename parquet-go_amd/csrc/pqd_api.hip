@@ -595,6 +595,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
   if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
+  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream)
+  if (fused && !is_bytes && (esz == 4 || esz == 8)) heavy = h->stream;
+  if (fused && is_bytes) heavy = h->stream;
   auto to_heavy = [&]() -> hipError_t {
     if (heavy == h->stream) return hipSuccess;
     hipError_t e = hipEventRecord(h->ev_ready, h->stream);
