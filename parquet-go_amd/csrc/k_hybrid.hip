@@ -708,13 +708,15 @@ __global__ __launch_bounds__(256) void k_pages_count(ChunkCtx c, int64_t *__rest
 }
 
 // One workgroup: the totals of the call, and in place of every block's value count the values in front of the block.
-__global__ __launch_bounds__(1024) void k_pages_finalize(int n_blocks, int64_t *__restrict__ block_sums, int64_t *__restrict__ totals) {
-  __shared__ int64_t s_wave[16];
+// (Four wavefronts: a workgroup of sixteen waits for room on a GPU that other chunks keep busy.)
+constexpr int kFinThreads = 256;
+__global__ __launch_bounds__(kFinThreads) void k_pages_finalize(int n_blocks, int64_t *__restrict__ block_sums, int64_t *__restrict__ totals) {
+  __shared__ int64_t s_wave[kFinThreads / 64];
   __shared__ unsigned long long s_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 4) s_tot[tid] = 0;
   __syncthreads();
-  for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+  for (int b0 = 0; b0 < n_blocks; b0 += kFinThreads) {
     const int64_t carry = (int64_t)s_tot[1];
     const int b = b0 + tid;
     int64_t sum[4] = {0, 0, 0, 0};
@@ -1014,12 +1016,12 @@ hipError_t launch_rle_only_levels(const ChunkCtx &c, int32_t *rep_out, int32_t *
 // page whose ReadPage returns an error).  out[0] = status, out[1] = page index or -1.
 // ---------------------------------------------------------------------------------------------
 // out[kDirectCount]: data pages whose index stream was expanded straight from the page (k_rle_only_pages, k_page_fused).
-__global__ __launch_bounds__(1024) void k_collect_status(ChunkCtx c, int32_t *out) {
+__global__ __launch_bounds__(256) void k_collect_status(ChunkCtx c, int32_t *out) {
   __shared__ int s_first, s_direct;
   if (threadIdx.x == 0) { s_first = 0x7FFFFFFF; s_direct = 0; }
   __syncthreads();
   int n_direct = 0;
-  for (int p = threadIdx.x; p < c.n_pages; p += 1024) {
+  for (int p = threadIdx.x; p < c.n_pages; p += 256) {
     int st = c.state[p].status;
     const int d = c.pages[p].data_idx;
     if (d >= 0) n_direct += c.streams[2 * c.nd + d].direct != 0;
@@ -1069,7 +1071,7 @@ __global__ void k_collect_status_done(ChunkCtx c, int32_t *out) {
 
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream) {
   if (c.n_pages <= 4096) {
-    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(1024), 0, stream, c, out);
+    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(256), 0, stream, c, out);   // (few wavefronts: placed at once on a busy GPU)
   } else {
     hipError_t e = hipMemsetAsync(out + 1, 0x7F, 4, stream);
     if (e != hipSuccess) return e;
@@ -1084,7 +1086,7 @@ hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t st
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, int64_t *block_sums, hipStream_t stream) {
   const int n_blocks = (c.n_pages + 255) / 256;
   if (n_blocks > 0) hipLaunchKernelGGL(k_pages_count, dim3(n_blocks), dim3(256), 0, stream, c, block_sums);
-  hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(1024), 0, stream, n_blocks, block_sums, totals);
+  hipLaunchKernelGGL(k_pages_finalize, dim3(1), dim3(kFinThreads), 0, stream, n_blocks, block_sums, totals);
   if (n_blocks > 0) hipLaunchKernelGGL(k_pages_values, dim3(n_blocks), dim3(256), 0, stream, c, block_sums);
   return hipGetLastError();
 }

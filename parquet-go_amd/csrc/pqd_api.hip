@@ -595,9 +595,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
   if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
-  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream)
-  if (fused && !is_bytes && (esz == 4 || esz == 8)) heavy = h->stream;
-  if (fused && is_bytes) heavy = h->stream;
+  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream, and
+  //  the run-header walk in front of it is the one of a wavefront per stream, whose workgroups are placed at once)
+  const bool fused_ran = fused && any_dict_enc && (is_bytes || esz == 4 || esz == 8);
+  if (fused_ran) { heavy = h->stream; if (h->opt[PQD_OPT_PRESCAN] < 0) wide_dict = false; }
+  // (and the variant of that walk with the smaller LDS footprint, unless a caller pinned the other)
+  const bool jump_dict = jump && !(fused_ran && h->opt[PQD_OPT_JUMP] < 0);
   auto to_heavy = [&]() -> hipError_t {
     if (heavy == h->stream) return hipSuccess;
     hipError_t e = hipEventRecord(h->ev_ready, h->stream);
@@ -631,7 +634,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         const uint8_t *dptr = dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
         const int dn = dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
         HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, t_lo, t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
-                                   shared_gpu && heavy == h->stream, h->opt[PQD_OPT_SPLIT], heavy));
+                                   fused_ran, h->opt[PQD_OPT_SPLIT], heavy));
       }
       p = q;
     }
@@ -668,7 +671,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       if (fused) { Prof pf(h, "k_page_fused");   // (the dictionary entries are the 8-byte descriptors of the strings)
         HIP_TRY(launch_page_fused(c8, static_cast<const uint8_t *>(h->dict_pairs.p), reinterpret_cast<uint8_t *>(pairs), max_dict_n,
                                   h->opt[PQD_OPT_FUSED] == 1 ? 1 : kFusedMinLen, h->stream)); }
-      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);
         if ((rc = expand_dict_groups(c8, static_cast<const uint8_t *>(h->dict_pairs.p), 8, reinterpret_cast<uint8_t *>(pairs)))) return rc; }
@@ -710,7 +713,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       if (direct_rle && any_dict_enc && (esz == 4 || esz == 8)) { Prof pf(h, "k_rle_only_pages"); HIP_TRY(launch_rle_only_pages(c, static_cast<const uint8_t *>(h->dict.p), dense_out, h->stream)); }
       if (fused && any_dict_enc && (esz == 4 || esz == 8)) { Prof pf(h, "k_page_fused");
         HIP_TRY(launch_page_fused(c, static_cast<const uint8_t *>(h->dict.p), dense_out, max_dict_n, h->opt[PQD_OPT_FUSED] == 1 ? 1 : kFusedMinLen, h->stream)); }
-      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump, h->stream)); }
+      { Prof pf(h, "k_hybrid_prescan(dict)"); HIP_TRY(launch_hybrid_prescan(c, 2 * nd, nd, wide_dict, jump_dict, h->stream)); }
       HIP_TRY(to_heavy());
       { Prof pf(h, "k_hybrid_expand<dict>", heavy);
         if ((rc = expand_dict_groups(c, static_cast<const uint8_t *>(h->dict.p), esz, dense_out))) return rc; }

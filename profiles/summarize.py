@@ -2,9 +2,9 @@
 """Condense rocprofv3 CSV output (see collect.sh) into the files kept in this directory:
 
   <tag>_kernel_stats.csv   per-kernel totals / averages of the --kernel-trace --stats run of bench.py
-  <tag>_expand_by_width.csv   average duration of the dictionary expand kernel per launch geometry
+  <tag>_expand_by_geometry.csv   average duration of the one-pass kernel (and of the tile expansion) per launch geometry
   <tag>_pmc.csv            per kernel: launches, mean FETCH_SIZE and WRITE_SIZE (KB, as rocprofv3 reports them)
-  traffic.json             HBM bytes per launch of the expand kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950
+  traffic.json             HBM bytes per launch of the one-pass kernel (k_page_fused) = (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950
                            correction for wide coalesced reads applied (FETCH_SIZE counts 128-byte requests as 64)
 """
 import csv
@@ -37,7 +37,7 @@ def main():
     agg = defaultdict(lambda: [0, 0.0])
     for f in find(os.path.join(out, "kt"), "kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
-            if "k_hybrid_expand" not in r["Kernel_Name"]:
+            if "k_page_fused" not in r["Kernel_Name"] and "k_hybrid_expand" not in r["Kernel_Name"]:
                 continue
             key = (short(r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("LDS_Block_Size", ""))
             e = agg[key]
@@ -70,7 +70,7 @@ def main():
     # the 4-byte dictionary gather instantiations (dictionary in LDS or in global memory) taken together
     tot = {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]}
     for k, d in pmc.items():
-        if "k_hybrid_expand<4" in k:
+        if "k_page_fused<unsigned int" in k:
             for c in tot:
                 tot[c][0] += d.get(c, [0, 0.0])[0]
                 tot[c][1] += d.get(c, [0, 0.0])[1]
@@ -81,7 +81,7 @@ def main():
     if tot["FETCH_SIZE"][0] and tot["WRITE_SIZE"][0]:
         fm = tot["FETCH_SIZE"][1] / tot["FETCH_SIZE"][0]
         wm = tot["WRITE_SIZE"][1] / tot["WRITE_SIZE"][0]
-        json.dump({"traffic": int((2 * fm + wm) * 1024), "unit": "bytes per launch of k_hybrid_expand<dict>, mean over the widths",
+        json.dump({"traffic": int((2 * fm + wm) * 1024), "unit": "bytes per launch of k_page_fused, mean over the widths",
                    "fetch_size_kb": round(fm, 1), "write_size_kb": round(wm, 1), "launches": tot["FETCH_SIZE"][0],
                    "values_per_gpu": cfg.get("values_per_gpu"), "page_values": cfg.get("page_values"), "widths": cfg.get("widths"),
                    "source": tag + "_pmc.csv"}, open(os.path.join(here, "traffic.json"), "w"), indent=1)
