@@ -215,7 +215,9 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
     const uint32_t qpos = j * (uint32_t)kFWin + 16u * (uint32_t)i;
     const uint8_t *p = base16 + (size_t)j * kFWin + 16 * i;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (qpos < qend + 48u && p < in_end) v = *reinterpret_cast<const uint4 *>(p);   // (its granule holds bytes of the buffer)
+    // only granules that hold bytes of the stream are read (in a call of several chunks the bytes behind a chunk's last
+    // page may not be mapped); what the ring holds beyond the stream's end is never used for a value that is kept
+    if (qpos < qend && p < in_end) v = *reinterpret_cast<const uint4 *>(p);
     return v;
   };
   auto put_vec = [&](uint32_t j, int i, uint4 v) {
@@ -255,16 +257,17 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
     typedef __attribute__((address_space(3))) uint32_t *LdsDst;
     typedef const __attribute__((address_space(1))) uint32_t *GlobalSrc;
     const uint32_t jl = R + 2u;
-    if (first && jl * (uint32_t)kFWin < qend + 48u) {
+    if (first && jl * (uint32_t)kFWin < qend) {
       const uint8_t *p = base16 + (size_t)jl * kFWin + 16 * lane;
+      const uint32_t qp = jl * (uint32_t)kFWin + 16u * (uint32_t)lane;   // position of this lane's first granule
       const uint32_t slot = jl & (uint32_t)(kFSlots - 1);
       uint8_t *dst = reinterpret_cast<uint8_t *>(ring32) + slot * (uint32_t)kFWin;
-      const bool whole = base16 + (size_t)(jl + 1u) * kFWin <= in_end;
+      const bool whole = (jl + 1u) * (uint32_t)kFWin <= qend;            // the window lies inside the stream
 #pragma unroll
       for (int k = 0; k < NV; k++)
-        if (whole || p + 1024 * k < in_end)    // (the granule of a lane that loads holds bytes of the buffer)
+        if (whole || qp + 1024u * (uint32_t)k < qend)    // (only granules that hold bytes of the stream)
           __builtin_amdgcn_global_load_lds((GlobalSrc)(p + 1024 * k), (LdsDst)(dst + 1024 * k), 16, 0, 0);
-      if (slot == 0 && lane < kFMirror / 16 && (whole || p < in_end))
+      if (slot == 0 && lane < kFMirror / 16 && (whole || qp < qend))
         __builtin_amdgcn_global_load_lds((GlobalSrc)p, (LdsDst)(reinterpret_cast<uint8_t *>(ring32) + kFRing), 16, 0, 0);
     }
     uint32_t n_list = 0, items = 0;
