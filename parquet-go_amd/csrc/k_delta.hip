@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
 // past it, a count that contradicts the page) leaves the page to k_delta_decode, which reproduces the reference's
 // behaviour on such input; delta_fast tells the two apart.
 //
-// The blocks of a page are then cut into units of 32 (4096 values), one wavefront each (k_delta_units).  The only
+// The blocks of a page are then cut into units of up to 64 (8192 values), one wavefront each (k_delta_units).  The only
 // thing that ties a block to the ones before it is the running value.  A unit stages its packed bytes in LDS (one
 // coalesced sweep; the loop that follows has no global loads, so its stores are never waited for), adds up the
 // deltas of every block - one block per lane, fields peeled off a bit buffer - and publishes the unit's total; it
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
 // output per lane.  The packed bytes are read from memory once.
 //
 // Work space: DeltaBlock[nb] | unit totals 2 x uint64[nu] | DeltaUnit[nu], with
-// nb = slots / 128 + 3 * pages + 8 and nu = slots / 4096 + pages + 8.  Per page the block table holds n_blocks
+// nb = slots / 128 + 3 * pages + 8 and nu = slots / 1024 + pages + 8 (room for the smallest units).  Per page the block table holds n_blocks
 // entries, then {first value (min_delta field)} and {stream start (min_delta field)}.
 // ---------------------------------------------------------------------------------------------
 struct DeltaWork {
@@ -421,13 +421,25 @@ struct DeltaWork {
   uint64_t *gsum;       // two words per unit: the unit's total, published by the unit itself
   DeltaUnit *units;
   int64_t n_units;
+  int32_t ushift;       // a unit is 2^ushift blocks (3 .. 6), chosen per call from the bytes the pages spend per value
+  int32_t win_bytes;    // LDS window over the packed bytes of a unit (the launch's dynamic LDS)
 };
 
+// A unit is 2^ushift blocks, as many as fit the LDS window (at most 64: one block per lane).  What a unit costs beyond
+// its values - its record, its table entries, the wait for its bytes, the totals of the units before it - is the same
+// for a small unit and a large one, so units are as large as the window allows (512 Mi INT64 values of 12-bit deltas:
+// 1.92 ms with 16 blocks per unit, 1.53 with 32, 1.32 with 64), and the window no larger than the unit needs (LDS per
+// wavefront sets how many are in flight per CU: 1.38 ms with a window a quarter larger).  A unit whose bytes outgrow
+// the window is decoded through a window that moves over its blocks (half again as slow).
+constexpr int kMaxUnitShift = 6, kMinUnitShift = 3;
+constexpr uint32_t kMaxUnitBlocks = 1u << kMaxUnitShift;
+constexpr int kMaxWinBytes = 13312;
+
 __device__ __forceinline__ int64_t delta_table_base(const PageIn &pi) { return (pi.slot_base >> 7) + 3 * (int64_t)pi.data_idx; }
-__device__ __forceinline__ int64_t delta_unit_base(const PageIn &pi) { return (pi.slot_base >> (7 + 5)) + (int64_t)pi.data_idx; }   // (7 + kUnitShift)
+__device__ __forceinline__ int64_t delta_unit_base(const PageIn &pi, int ushift) { return (pi.slot_base >> (7 + ushift)) + (int64_t)pi.data_idx; }
 
 // -> the number of blocks, or -1 when the page is left to k_delta_decode
-__device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int lane,
+__device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int ushift, int lane,
                                               int64_t *src_off_out, uint64_t *first_out) {
   if (lane == 0) ps->delta_fast = 0;
   const int64_t cnt = ps->cnt;
@@ -530,8 +542,9 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     if (lane < n_true) {
       tb[blk] = DeltaBlock{data_off, widths, md};
       // the byte range of the unit the block belongs to
-      if ((blk & 31u) == 0u) pu[blk >> 5].win_start = data_off;                                   // (kUnitBlocks = 32)
-      if ((blk & 31u) == 31u || blk + 1u == n_blocks) pu[blk >> 5].win_end = data_off + dbytes;
+      const uint32_t ublocks = 1u << ushift;
+      if ((blk & (ublocks - 1u)) == 0u) pu[blk >> ushift].win_start = data_off;
+      if ((blk & (ublocks - 1u)) == ublocks - 1u || blk + 1u == n_blocks) pu[blk >> ushift].win_end = data_off + dbytes;
     }
     const int last = n_true - 1;
     const uint32_t pos_last = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)pj64), last);
@@ -558,13 +571,13 @@ __global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, i
   const int p = c.streams[2 * c.nd + d].page;
   const PageIn &pi = c.pages[p];
   const int64_t nvp = pi.num_values > 0 ? pi.num_values : 0;
-  const int64_t ub = delta_unit_base(pi);
-  const int64_t range = ((pi.slot_base + nvp) >> 12) - (pi.slot_base >> 12) + 1;
+  const int64_t ub = delta_unit_base(pi, w.ushift);
+  const int64_t range = ((pi.slot_base + nvp) >> (7 + w.ushift)) - (pi.slot_base >> (7 + w.ushift)) + 1;
   int64_t src_off = 0;
   uint64_t first_raw = 0;
-  const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, lane, &src_off, &first_raw) : -1;
+  const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, w.ushift, lane, &src_off, &first_raw) : -1;
   // the page's units: the ones its blocks fill get their records, the rest of its range holds nothing
-  const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + 31) / 32);     // (a stream of one value still has its first value to write)
+  const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + ((int64_t)1 << w.ushift) - 1) >> w.ushift);     // (a stream of one value still has its first value to write)
   for (int64_t j = lane; j < range; j += 64) {
     if (ub + j >= w.n_units) continue;
     DeltaUnit *r = w.units + ub + j;
@@ -586,9 +599,6 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // a value every la
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-constexpr int kUnitShift = 5;            // a unit is 32 blocks = 4096 values
-constexpr uint32_t kUnitBlocks = 1u << kUnitShift;
-constexpr int kWinBytes = 8192;         // LDS window over the packed bytes of a unit
 constexpr int kWinSlack = 64;           // bytes past the window that a lane's last reads may touch (never used)
 constexpr uint32_t kSpinLimit = 1u << 22;
 
@@ -667,10 +677,12 @@ __device__ __forceinline__ T delta_block_sum(const uint32_t *win, uint32_t r, ui
 // total, collect the totals of the units before it in the page, decode two blocks per step.
 template <class T>
 __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
-  __shared__ uint4 win4[(kWinBytes + kWinSlack) / 16];
-  __shared__ DeltaBlock s_ent[kUnitBlocks];
-  __shared__ uint64_t s_prev[kUnitBlocks];
-  __shared__ uint32_t s_tot[kUnitBlocks];
+  extern __shared__ uint4 win4[];           // w.win_bytes + kWinSlack
+  __shared__ DeltaBlock s_ent[kMaxUnitBlocks];
+  __shared__ uint64_t s_prev[kMaxUnitBlocks];
+  __shared__ uint32_t s_tot[kMaxUnitBlocks];
+  const uint32_t kUnitBlocks = 1u << w.ushift;
+  const uint32_t kWinBytes = (uint32_t)w.win_bytes;
   __shared__ uint4 s_stage[sizeof(T) == 8 ? 128 : 1];
   uint32_t *win = reinterpret_cast<uint32_t *>(win4);
   const int lane = threadIdx.x;
@@ -699,10 +711,10 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   // The unit's bytes, when the window holds them all, are asked for at once with the table entries (the record
   // names the range); otherwise the window moves over the blocks.
   uint32_t win_a0 = win_start - ((src_al + win_start) & 15u);
-  const bool one_window = nb_here != 0u && win_end - win_a0 <= (uint32_t)kWinBytes;
+  const bool one_window = nb_here != 0u && win_end - win_a0 <= kWinBytes;
   auto fill_window = [&](uint32_t a0, uint32_t end) {
     // (a0 may lie up to 15 bytes in front of the stream: signed from here on)  All loads first, then the LDS writes.
-    constexpr int kSweeps = (kWinBytes + 1023) / 1024;
+    constexpr int kSweeps = (kMaxWinBytes + 1023) / 1024;   // (sweeps past `end` load and write nothing)
     const int64_t o0 = (int64_t)(int32_t)a0 + 16 * lane;
     uint4 x[kSweeps];
 #pragma unroll
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   auto stage = [&](uint32_t bs) -> uint32_t {
     const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)E.data_off, (int)bs);
     const uint32_t a0 = start - ((src_al + start) & 15u);
-    const bool fits = (uint32_t)lane >= bs && (uint32_t)lane < nb_here && data_end - a0 <= (uint32_t)kWinBytes;
+    const bool fits = (uint32_t)lane >= bs && (uint32_t)lane < nb_here && data_end - a0 <= kWinBytes;
     const uint64_t fm = __ballot(fits) >> bs;
     uint32_t n = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
     if (bs + n < nb_here) n &= ~1u;                 // steps take blocks in pairs
@@ -777,7 +789,6 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   if (quick) {
     // (four steps at a time without a branch between them, so that the LDS reads of one step overlap the arithmetic
     //  of another; steps past the unit's last block unpack block 0 again and keep nothing)
-#pragma unroll
     for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
       if (2u * (uint32_t)i0 < nb_here) {
 #pragma unroll
@@ -838,7 +849,6 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
 
   // ---- values ----
   if (quick) {
-#pragma unroll
     for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
       if (2u * (uint32_t)i0 >= nb_here) break;
 #pragma unroll
@@ -940,25 +950,40 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   }
 }
 
+// (sized for the smallest units)
 size_t delta_work_bytes(int64_t slots, int nd) {
-  const size_t nb = (size_t)slots / 128 + 3 * (size_t)nd + 8, nu = (size_t)slots / 4096 + (size_t)nd + 8;
+  const size_t nb = (size_t)slots / 128 + 3 * (size_t)nd + 8, nu = ((size_t)slots >> (7 + kMinUnitShift)) + (size_t)nd + 8;
   return 16 * nb + (16 + sizeof(DeltaUnit)) * nu + 128;
 }
 
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               hipStream_t stream) {
+                               double bytes_per_value, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (work) {
-    const size_t nb = (size_t)slots / 128 + 3 * (size_t)c.nd + 8, nu = (size_t)slots / 4096 + (size_t)c.nd + 8;
+    // Units as large as the window allows, the window as small as the units need: from the bytes the pages spend per
+    // value (0: not known - the lengths of byte arrays, which share their pages with the bytes: 32 blocks, 6.5 KiB).
+    int ushift = 5, win_bytes = 6656;
+    if (bytes_per_value > 0.0) {
+      const double block_bytes = 128.0 * bytes_per_value;     // (block headers included: it is what the page spends)
+      ushift = kMaxUnitShift;
+      while (ushift > kMinUnitShift && block_bytes * (double)(1 << ushift) + 32.0 > (double)kMaxWinBytes) ushift--;
+      win_bytes = ((int)(block_bytes * (double)(1 << ushift) * 1.01) + 64 + 511) / 512 * 512;
+      if (win_bytes < 2048) win_bytes = 2048;
+      if (win_bytes > kMaxWinBytes) win_bytes = kMaxWinBytes;
+    }
+    const size_t nb = (size_t)slots / 128 + 3 * (size_t)c.nd + 8, nu = ((size_t)slots >> (7 + kMinUnitShift)) + (size_t)c.nd + 8;
     DeltaWork w;
     w.blocks = static_cast<DeltaBlock *>(work);
     w.gsum = reinterpret_cast<uint64_t *>(w.blocks + nb);
     w.units = reinterpret_cast<DeltaUnit *>((reinterpret_cast<uintptr_t>(w.gsum + 2 * nu) + 63) & ~(uintptr_t)63);
-    w.n_units = (int64_t)((size_t)slots / 4096 + (size_t)c.nd);
+    w.n_units = (int64_t)(((size_t)slots >> (7 + ushift)) + (size_t)c.nd);
+    w.ushift = ushift;
+    w.win_bytes = win_bytes;
     hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
     const dim3 grid((unsigned)w.n_units);
-    if (elem_size == 4) hipLaunchKernelGGL(k_delta_units<uint32_t>, grid, dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
-    else hipLaunchKernelGGL(k_delta_units<uint64_t>, grid, dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
+    const size_t shmem = (size_t)win_bytes + kWinSlack;
+    if (elem_size == 4) hipLaunchKernelGGL(k_delta_units<uint32_t>, grid, dim3(64), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
+    else hipLaunchKernelGGL(k_delta_units<uint64_t>, grid, dim3(64), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
   }
   if (elem_size == 4)
     hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel);

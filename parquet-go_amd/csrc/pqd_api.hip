@@ -679,13 +679,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
       HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, h->stream)); }
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, h->stream)); }
+      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
       { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
     }
@@ -728,7 +728,16 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     }
     if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-    if (any_delta) { Prof pf(h, "k_delta_decode"); HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, h->stream)); }
+    if (any_delta) {
+      // what the DELTA_BINARY_PACKED pages spend per value (levels included, which only makes the units smaller)
+      int64_t db = 0, dv = 0;
+      for (int p = 0; p < n_pages; p++) {
+        const PageIn &pi = h->h_pages[(size_t)p];
+        if (pi.data_idx >= 0 && pi.encoding == PQD_ENC_DELTA_BINARY_PACKED && pi.num_values > 0) { db += pi.body_len; dv += pi.num_values; }
+      }
+      Prof pf(h, "k_delta_decode");
+      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, h->stream));
+    }
     if (nullable && slots > 0) {
       Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
       if (plain_scatter)

@@ -65,8 +65,9 @@ hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, ui
 // work: delta_work_bytes(slots, pages) bytes (slots = the level slots of the call's data pages), or nullptr to
 // decode every page with the wavefront-per-page kernel
 size_t delta_work_bytes(int64_t slots, int nd);
+// bytes_per_value: what the pages of this encoding spend per value (sets how many blocks a wavefront takes at once); 0: not known
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               hipStream_t stream);
+                               double bytes_per_value, hipStream_t stream);
 
 // ---- k_bytes.hip ----
 // dict_pages == nullptr: the PLAIN data pages; else the listed dictionary pages
