@@ -24,12 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--values", type=int, default=256 << 20, help="values per GPU in the column chunk")
     ap.add_argument("--page-values", type=int, default=1 << 20)
     ap.add_argument("--widths", type=str, default="1,2,4,8,12,16,20")
-    ap.add_argument("--cpu-pages", type=int, default=24, help="pages per width decoded by the CPU oracle (baseline sample)")
+    ap.add_argument("--cpu-pages", type=int, default=64, help="pages per width decoded by the CPU oracle (baseline sample)")
     ap.add_argument("--handles", type=int, default=7, help="chunks in flight (one handle / HIP stream each)")
     ap.add_argument("--depth", type=int, default=2, help="steps in flight (sets of handles)")
     ap.add_argument("--no-cpu", action="store_true")
