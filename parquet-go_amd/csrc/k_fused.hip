@@ -43,7 +43,13 @@ struct __attribute__((aligned(16))) FusedList {
   FusedEntry e[kFRunCap + 2];
 };
 
-constexpr int kFusedFixedLds = kFRing + kFMirror + kFRunCap * 4 + 2 * (int)sizeof(FusedList);
+// What the walk leaves per step: the positions of the headers it passed, where it stands, which window it was on.
+struct __attribute__((aligned(16))) FusedPos {
+  uint32_t n, q_end, R, last;
+  uint32_t pos[kFRunCap];
+};
+
+constexpr int kFusedFixedLds = kFRing + kFMirror + 3 * (int)sizeof(FusedPos) + 2 * (int)sizeof(FusedList);
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
@@ -173,7 +179,7 @@ __device__ __forceinline__ void fused_expand(const FusedList *L, const uint32_t 
 }
 
 // T: uint32_t / uint64_t dictionary entries.  DMODE 1: the whole dictionary in LDS; 2: its head in LDS, the rest gathered
-// from global memory.  NW wavefronts: one walks, NW - 1 expand.
+// from global memory.  NW wavefronts: one walks, one makes the lists, NW - 2 expand.
 template <class T, int DMODE, int NW>
 __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
                                                         int dict_lds_bytes, int min_len) {
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
   // lists and the dictionary
   uint32_t *ring32 = reinterpret_cast<uint32_t *>(lds);
   uint4 *ring4 = reinterpret_cast<uint4 *>(ring32);
-  uint32_t *s_pos = reinterpret_cast<uint32_t *>(lds + kFRing + kFMirror);   // header positions of one step
-  FusedList *lists = reinterpret_cast<FusedList *>(s_pos + kFRunCap);
+  FusedPos *s_pos = reinterpret_cast<FusedPos *>(lds + kFRing + kFMirror);   // header positions of three steps
+  FusedList *lists = reinterpret_cast<FusedList *>(s_pos + 3);
   T *s_dict = reinterpret_cast<T *>(lds + kFusedFixedLds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (int)rfl((uint32_t)tid >> 6);
@@ -226,8 +232,7 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
     if (slot == 0 && i < kFMirror / 16) ring4[kFRing / 16 + i] = v;
   };
 
-  for (uint32_t j = 0; j < 2; j++)
-    for (int i = tid; i < kFWin / 16; i += NT) put_vec(j, i, load_vec(j, i));
+  for (int i = tid; i < kFWin / 16; i += NT) put_vec(0u, i, load_vec(0u, i));
   if ((reinterpret_cast<uintptr_t>(dict) & 15u) == 0) {
     const int nvec = (int)((dict_lds_n * sizeof(T) + 15) / 16);
     for (int i = tid; i < nvec; i += NT) reinterpret_cast<uint4 *>(s_dict)[i] = reinterpret_cast<const uint4 *>(dict)[i];
@@ -236,27 +241,31 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
   }
   __syncthreads();
 
-  // ---- the walk (wavefront 0; everything wave-uniform) ----
-  // A step of the walk covers the headers of one window, or kFRunCap of them when the window holds more; the groups of a
-  // bit-packed run that start beyond the window are carried into the next step.  While window R is walked for the first
-  // time, window R + 2 comes in (the expanding wavefronts are on window R - 1 or R then, and read one window ahead).
-  uint32_t q = a, o32 = 0, R = 0;
-  uint32_t cp = 0, cg = 0, co = 0;   // carried groups: position of the first, how many, index of their first value
-  bool fin = false, bail = false, first = true;
+  // ---- three stages, one barrier per step ----
+  // Wavefront 0 walks: a step covers the headers of one window (kFRunCap of them when it holds more) and leaves
+  // nothing but their positions.  Wavefront 1 turns the positions of the step before into the list of runs: what each
+  // run is, where its values and work items start; the groups of a bit-packed run that start beyond the window are
+  // carried into the next list.  The other wavefronts expand the list of the step before that.  While window R is
+  // walked for the first time, window R + 1 comes in: the walk stays inside its window - a header in a window's last
+  // byte (its second byte may belong to the window on its way) is left to the next step - the list maker and the
+  // expanding wavefronts are at most one and two windows behind and read a few bytes ahead, which makes four slots.
   uint32_t vz;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vz));   // a zero the compiler keeps in a vector register (see the hop loop)
   typedef __attribute__((address_space(3))) uint32_t *Lds32;
-  const uint32_t ring_addr = (uint32_t)(uintptr_t)(Lds32)ring32, pos_addr = (uint32_t)(uintptr_t)(Lds32)s_pos;
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(Lds32)ring32;
 
-  auto walk = [&](FusedList *L) {
+  // -- the walk (wavefront 0; everything wave-uniform) --
+  uint32_t q = a, R = 0;
+  bool first = true;
+  auto hop_step = [&](FusedPos *P) {
     const uint32_t E = (R + 1u) * (uint32_t)kFWin;
-    const uint32_t whi = E < qend ? E : qend;
-    // Window R + 2 comes in while window R is walked: loads that write LDS themselves (no registers held across the
-    // walk; a wavefront-instruction fills 64 x 16 consecutive bytes), waited for at the step's barrier.
+    const uint32_t whi = E - 1u < qend ? E - 1u : qend;
+    // loads that write LDS themselves (no registers held across the walk; a wavefront-instruction fills 64 x 16
+    // consecutive bytes), waited for at the step's barrier
     constexpr int NV = kFWin / 16 / 64;
     typedef __attribute__((address_space(3))) uint32_t *LdsDst;
     typedef const __attribute__((address_space(1))) uint32_t *GlobalSrc;
-    const uint32_t jl = R + 2u;
+    const uint32_t jl = R + 1u;
     if (first && jl * (uint32_t)kFWin < qend) {
       const uint8_t *p = base16 + (size_t)jl * kFWin + 16 * lane;
       const uint32_t qp = jl * (uint32_t)kFWin + 16u * (uint32_t)lane;   // position of this lane's first granule
@@ -270,6 +279,61 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
       if (slot == 0 && lane < kFMirror / 16 && (whole || qp < qend))
         __builtin_amdgcn_global_load_lds((GlobalSrc)p, (LdsDst)(reinterpret_cast<uint8_t *>(ring32) + kFRing), 16, 0, 0);
     }
+    uint32_t n = 0;
+    if (q < whi) {
+      // The chain itself - header at q, next header at q + its length + the run's bytes - is all that has to happen one
+      // run after the other, and a lone wavefront issues an instruction every four cycles or so: the loop does nothing
+      // but note the position and step on (vector instructions on a value all lanes share: no trips between the scalar
+      // and the vector side; written out by hand, 21 instructions a run).  It does not look at what it steps over: a
+      // header of three bytes or more, an empty run or a run reaching past the stream is found when the list is made,
+      // and then nothing of the page is kept.
+      uint32_t vq = q + vz;
+      uint32_t vpp = (uint32_t)(uintptr_t)(Lds32)P->pos + vz;
+      const uint32_t cap = (uint32_t)kFRunCap;
+      uint32_t va, b0, b1, g, t;
+      const uint32_t v_negnb = vz - nb_rle, v_onb = vz + 1u + nb_rle;
+      asm volatile(
+          "s_waitcnt lgkmcnt(0)\n"
+          "1:\n"
+          "v_and_b32 %[va], 0x7fff, %[vq]\n"
+          "v_add_u32 %[va], %[rb], %[va]\n"
+          "ds_read_u8 %[b0], %[va]\n"
+          "ds_read_u8 %[b1], %[va] offset:1\n"
+          "ds_write_b32 %[vpp], %[vq]\n"
+          "v_add_u32 %[vpp], 4, %[vpp]\n"
+          "s_add_u32 %[n], %[n], 1\n"
+          "s_waitcnt lgkmcnt(1)\n"                          // LDS operations complete in order: both reads are in
+          "v_bfe_u32 %[g], %[b0], 1, 6\n"                   // one-byte header: groups or values
+          "v_and_b32 %[b1], 0x7f, %[b1]\n"
+          "v_lshl_or_b32 %[b1], %[b1], 6, %[g]\n"           // two-byte header
+          "v_cmp_lt_u32 vcc, 0x7f, %[b0]\n"
+          "v_cndmask_b32 %[g], %[g], %[b1], vcc\n"
+          "v_mad_i32_i24 %[t], %[g], %[w], %[negnb]\n"      // bit-packed: w bytes per group, against the RLE value's bytes
+          "v_and_b32 %[b0], 1, %[b0]\n"
+          "v_mad_i32_i24 %[vq], %[b0], %[t], %[vq]\n"
+          "v_addc_co_u32 %[vq], vcc, %[onb], %[vq], vcc\n"  // + header byte + RLE value bytes + second header byte
+          "v_cmp_gt_u32 vcc, %[whi], %[vq]\n"
+          "s_cbranch_vccz 2f\n"
+          "s_cmp_lt_u32 %[n], %[cap]\n"
+          "s_cbranch_scc1 1b\n"
+          "2:\n"
+          : [vq] "+v"(vq), [vpp] "+v"(vpp), [n] "+s"(n), [va] "=&v"(va), [b0] "=&v"(b0), [b1] "=&v"(b1), [g] "=&v"(g), [t] "=&v"(t)
+          : [rb] "s"(ring_addr), [w] "s"(uw), [negnb] "v"(v_negnb), [onb] "v"(v_onb), [whi] "s"(whi), [cap] "s"(cap)
+          : "vcc", "scc", "memory");
+      q = rfl(vq);
+    }
+    if (lane == 0) { P->n = n; P->q_end = q; P->R = R; P->last = q >= qend ? 1u : 0u; }
+    first = q >= whi;
+    if (first) R++;
+  };
+
+  // -- the lists (wavefront 1) --
+  uint32_t o32 = 0;
+  uint32_t cp = 0, cg = 0, co = 0;   // carried groups: position of the first, how many, index of their first value
+  bool fin = false, bail = false;
+  auto make_list = [&](const FusedPos *P, FusedList *L) {
+    const uint32_t n = rfl(P->n), qs = rfl(P->q_end), Rs = rfl(P->R), plast = rfl(P->last);
+    const uint32_t E = (Rs + 1u) * (uint32_t)kFWin;
     uint32_t n_list = 0, items = 0;
     if (cg) {
       const uint32_t fit = (E - cp + uw - 1u) / uw;        // its groups that start before E (cp < E)
@@ -278,56 +342,14 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
       n_list = 1; items = here;
       cp += here * uw; co += here * 8u; cg -= here;
     }
-    if (cg == 0 && !fin && !bail && q < whi) {
-      // The chain itself - header at q, next header at q + its length + the run's bytes - is all that has to happen one
-      // run after the other, and a lone wavefront issues an instruction every four cycles or so: the loop does nothing
-      // but note the position and step on (vector instructions on a value all lanes share: no trips between the scalar
-      // and the vector side; written out by hand, 21 instructions a run).  It does not look at what it steps over: a header of three bytes or more, an empty run or
-      // a run reaching past the stream is found afterwards, and then nothing of the step is used.
-      uint32_t vq = q + vz;
-      uint32_t vpp = pos_addr + vz;
-      uint32_t n = 0;
-      const uint32_t cap = (uint32_t)kFRunCap - n_list;
-      {
-        uint32_t va, b0, b1, g, t;
-        const uint32_t v_negnb = vz - nb_rle, v_onb = vz + 1u + nb_rle;
-        asm volatile(
-            "s_waitcnt lgkmcnt(0)\n"
-            "1:\n"
-            "v_and_b32 %[va], 0x7fff, %[vq]\n"
-            "v_add_u32 %[va], %[rb], %[va]\n"
-            "ds_read_u8 %[b0], %[va]\n"
-            "ds_read_u8 %[b1], %[va] offset:1\n"
-            "ds_write_b32 %[vpp], %[vq]\n"
-            "v_add_u32 %[vpp], 4, %[vpp]\n"
-            "s_add_u32 %[n], %[n], 1\n"
-            "s_waitcnt lgkmcnt(1)\n"                          // LDS operations complete in order: both reads are in
-            "v_bfe_u32 %[g], %[b0], 1, 6\n"                   // one-byte header: groups or values
-            "v_and_b32 %[b1], 0x7f, %[b1]\n"
-            "v_lshl_or_b32 %[b1], %[b1], 6, %[g]\n"           // two-byte header
-            "v_cmp_lt_u32 vcc, 0x7f, %[b0]\n"
-            "v_cndmask_b32 %[g], %[g], %[b1], vcc\n"
-            "v_mad_i32_i24 %[t], %[g], %[w], %[negnb]\n"      // bit-packed: w bytes per group, against the RLE value's bytes
-            "v_and_b32 %[b0], 1, %[b0]\n"
-            "v_mad_i32_i24 %[vq], %[b0], %[t], %[vq]\n"
-            "v_addc_co_u32 %[vq], vcc, %[onb], %[vq], vcc\n"  // + header byte + RLE value bytes + second header byte
-            "v_cmp_gt_u32 vcc, %[whi], %[vq]\n"
-            "s_cbranch_vccz 2f\n"
-            "s_cmp_lt_u32 %[n], %[cap]\n"
-            "s_cbranch_scc1 1b\n"
-            "2:\n"
-            : [vq] "+v"(vq), [vpp] "+v"(vpp), [n] "+s"(n), [va] "=&v"(va), [b0] "=&v"(b0), [b1] "=&v"(b1), [g] "=&v"(g), [t] "=&v"(t)
-            : [rb] "s"(ring_addr), [w] "s"(uw), [negnb] "v"(v_negnb), [onb] "v"(v_onb), [whi] "s"(whi), [cap] "s"(cap)
-            : "vcc", "scc", "memory");
-      }
-      q = rfl(vq);
-      if (q > qend) bail = true;       // a run the stream does not hold whole
+    if (n > 0 && !fin && !bail) {
+      if (cg != 0 || qs > qend) bail = true;       // (headers inside a run that goes on; a run the stream does not hold whole)
       // What each noted run is, and where its values and items start: one run per lane, wave prefix sums.
       for (uint32_t b = 0; b < n && !bail; b += 64u) {
         const uint32_t nbt = n - b < 64u ? n - b : 64u;
         const bool lastb = b + 64u >= n;
         const bool in = (uint32_t)lane < nbt;
-        const uint32_t posv = in ? s_pos[b + (uint32_t)lane] : a;
+        const uint32_t posv = in ? P->pos[b + (uint32_t)lane] : a;
         const uint32_t ro = posv & (uint32_t)(kFRing - 1), dj = ro >> 2, sj = (ro & 3u) * 8u;
         const uint32_t e0 = ring32[dj], e1 = ring32[dj + 1], e2 = ring32[dj + 2];
         const uint32_t y0 = __builtin_amdgcn_alignbit(e1, e0, sj), y1 = __builtin_amdgcn_alignbit(e2, e1, sj);
@@ -336,14 +358,14 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
         const uint32_t hlen = 1u + two, isbp = header & 1u, g = header >> 1;
         if (__ballot(in && ((y0 & 0x8080u) == 0x8080u || g == 0u))) { bail = true; break; }   // not for this kernel
         const uint32_t val = (uint32_t)((((uint64_t)y1 << 32) | y0) >> (8u * hlen)) & rle_mask;   // RLE value: the low 32 bits (encodingread.go:160)
-        const uint32_t P = posv + hlen;
+        const uint32_t Pp = posv + hlen;
         const uint32_t nvi = in ? g << (isbp * 3u) : 0u;
         const uint32_t incl_v = wave_incl_sum(nvi);
         uint32_t iti = in ? (isbp ? g : (nvi + 7u) >> 3) : 0u;
         uint32_t nv_here = nvi;
         // only the last run walked can reach beyond the window: its groups that start at E or later are carried
-        if (lastb && q > E && __builtin_amdgcn_readlane((int)isbp, (int)nbt - 1)) {
-          const uint32_t Pl = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)nbt - 1);
+        if (lastb && qs > E && __builtin_amdgcn_readlane((int)isbp, (int)nbt - 1)) {
+          const uint32_t Pl = (uint32_t)__builtin_amdgcn_readlane((int)Pp, (int)nbt - 1);
           const uint32_t gl = (uint32_t)__builtin_amdgcn_readlane((int)g, (int)nbt - 1);
           const uint32_t sl = o32 + (uint32_t)__builtin_amdgcn_readlane((int)(incl_v - nvi), (int)nbt - 1);
           const uint32_t fit = Pl >= E ? 0u : (E - Pl + uw - 1u) / uw;
@@ -354,27 +376,27 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
           }
         }
         const uint32_t incl_i = wave_incl_sum(iti);
-        if (in) L->e[n_list + (uint32_t)lane] = FusedEntry{o32 + incl_v - nvi, isbp ? P : val, items + incl_i - iti, nv_here | (isbp << 31)};
+        if (in) L->e[n_list + (uint32_t)lane] = FusedEntry{o32 + incl_v - nvi, isbp ? Pp : val, items + incl_i - iti, nv_here | (isbp << 31)};
         const uint64_t full = __ballot(in && o32 + incl_v >= ucnt);   // the run that completes the page's count
         if (full) {
           fin = true;
           // runs or bytes behind it: the reference reads them too, and may fail on them
-          if ((uint32_t)__builtin_ctzll(full) != nbt - 1u || !lastb || q != qend) bail = true;
+          if ((uint32_t)__builtin_ctzll(full) != nbt - 1u || !lastb || qs != qend) bail = true;
         }
         o32 += (uint32_t)__builtin_amdgcn_readlane((int)incl_v, (int)nbt - 1);
         items += (uint32_t)__builtin_amdgcn_readlane((int)incl_i, (int)nbt - 1);
         n_list += nbt;
       }
     }
-    if (!fin && !bail && cg == 0 && q >= qend) bail = true;   // the stream holds too few values
+    if (!fin && !bail && cg == 0 && plast) bail = true;   // the stream holds too few values
     if (lane == 0) { L->n = n_list; L->items = items; L->flags = ((fin && cg == 0) ? 1u : 0u) | (bail ? 2u : 0u); }
-    first = cg != 0 || q >= whi;
-    if (first) R++;
   };
 
   // the walk is the one serial chain of the page: its wavefront goes first whenever it has an instruction ready
-  if (wave == 0) __builtin_amdgcn_s_setprio(3);
-  if (wave == 0) walk(&lists[0]);
+  if (wave == 0) { __builtin_amdgcn_s_setprio(3); hop_step(&s_pos[0]); }
+  __syncthreads();
+  if (wave == 0) hop_step(&s_pos[1]);
+  else if (wave == 1) make_list(&s_pos[0], &lists[0]);
   __syncthreads();
 
   bool bad_index = false;
@@ -384,10 +406,12 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
     const uint32_t fl = rfl(L->flags);
     if (fl & 2u) { left = true; break; }
     if (wave == 0) {
-      if (!(fl & 1u)) walk(&lists[(r + 1u) & 1u]);
+      hop_step(&s_pos[(r + 2u) % 3u]);
+    } else if (wave == 1) {
+      if (!(fl & 1u)) make_list(&s_pos[(r + 1u) % 3u], &lists[(r + 1u) & 1u]);
     } else {
       switch (w) {
-#define PQD_CASE(W) case W: fused_expand<T, DMODE, W>(L, ring32, s_dict, dict, dict_n, dict_lds_n, out, ucnt, wave - 1, NW - 1, lane, bad_index); break;
+#define PQD_CASE(W) case W: fused_expand<T, DMODE, W>(L, ring32, s_dict, dict, dict_n, dict_lds_n, out, ucnt, wave - 2, NW - 2, lane, bad_index); break;
         PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
         PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
         PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
@@ -405,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
   if (left) return;    // (uniform) the general path decodes the stream and finds whatever is wrong with it
   if (tid == 0) {
     if (any_bad) atomicCAS(&c.state[sp->page].status, 0, PQD_ERR_MALFORMED);
-    sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)o32;
+    sp->direct = 1; sp->n_runs = 0; sp->decoded = (int64_t)cnt;
   }
 }
 
