@@ -4,12 +4,13 @@
 // The run-header walk of an RLE / bit-packed hybrid stream is a chain (the place of a header is known only after the
 // header before it), so a page is walked by one wavefront whatever else happens.  Run tables written by one kernel and
 // expanded by another make every page byte cross the memory bus twice and put the two serial steps of a chunk one
-// behind the other; here a workgroup owns a page: wavefront 0 follows the chain through a ring of stream bytes in LDS
-// and leaves, per step (a window of the ring, or kFRunCap runs of it), a short list of runs; the other wavefronts turn
-// the list of the step before into values (unpack, dictionary lookup, stores) out of the same ring.  One barrier per
-// step.  What bounds it: alone on the GPU a page takes as long as its walk (about 75 ns a run); with two or three
-// pages per CU in flight - several chunks decoded side by side, or a call of many pages - the memory system
-// (about 4.6 TB/s of page bytes read and values written).
+// behind the other; here a workgroup owns a page and works on it in three stages: wavefront 0 follows the chain
+// through a ring of stream bytes in LDS and notes, per step (a window of the ring, or kFRunCap runs of it), where the
+// headers are; wavefront 1 turns the positions of the step before into a short list of runs; the other wavefronts
+// turn the list of the step before that into values (unpack, dictionary lookup, stores) out of the same ring.  One
+// barrier per step.  What bounds it: alone on the GPU a page takes as long as its walk (about 75 ns a run and 0.3 us a
+// step); with two or three pages per CU in flight - several chunks decoded side by side, or a call of many pages -
+// the memory system (about 4.6 TB/s of page bytes read and values written).
 //
 // Only clean streams are finished here: headers of one or two bytes, no empty runs, every run inside the stream, the
 // stream ending with the run that completes the page's count.  Anything else leaves the stream to the general path
