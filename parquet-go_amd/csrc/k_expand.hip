@@ -593,7 +593,7 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
 
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int tile_lo, int tile_hi,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, bool leftover, int split_mode, hipStream_t stream) {
+                              int n_cu, int split_mode, hipStream_t stream) {
   if (tile_hi <= tile_lo) return hipSuccess;
   const int n_tiles = tile_hi - tile_lo;   // tiles of this launch (grid sizing)
   ExpandArgs a;
@@ -609,15 +609,11 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   // split_mode 0 / 1 pins the choice between the plain gather and the variant below that keeps the head of a mid-size
   // dictionary in LDS (tests); -1 takes the latter, which also finishes a batch of chunks decoded side by side a little
   // sooner (4.65 against 4.75 ms for the seven chunks of the benchmark) although each of its workgroups needs a whole CU.
-  // leftover: the one-pass kernel ran before and has most likely left nothing (the kernel then returns at once) - but
-  // the workgroups have to be placed first, and on a GPU full of other chunks' workgroups that takes as long as their
-  // LDS does to come free: a launch of few, small workgroups (dictionary gathered from memory) is through in a moment,
-  // and still decodes what a page or two may have left.
-  const bool no_split = split_mode == 0 || leftover;
+  const bool no_split = split_mode == 0;
   if (dict_bytes <= 48 * 1024 || !fixed48 || dict_bytes > 1024 * 1024 || no_split) {
     // small dictionaries: whole dictionary in the LDS of every block, several 256-thread blocks per CU.
     // Large ones of other element sizes, and very large ones: gathered from L2 / HBM.
-    const bool lds = dict_bytes > 0 && dict_bytes <= 48 * 1024 && !leftover;
+    const bool lds = dict_bytes > 0 && dict_bytes <= 48 * 1024;
     a.dict_lds_n = lds ? dict_n : 0;
     a.dict_lds_bytes = lds ? (int)dict_bytes : 0;
     set_group_layout(a, 254, stage_bytes);
@@ -626,7 +622,7 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     int grid = n_cu * per_cu;
-    if (leftover && grid > 64) grid = 64;
+
     if (grid > n_tiles) grid = n_tiles;
     if (esz == 4) return lds ? launch_expand(&k_hybrid_expand<4, 1, 1, 256>, a, grid, 256, shmem, stream)
                              : launch_expand(&k_hybrid_expand<4, 0, 1, 256>, a, grid, 256, shmem, stream);

@@ -595,12 +595,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
   if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
-  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream, and
-  //  the run-header walk in front of it is the one of a wavefront per stream, whose workgroups are placed at once)
+  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream)
   const bool fused_ran = fused && any_dict_enc && (is_bytes || esz == 4 || esz == 8);
-  if (fused_ran) { heavy = h->stream; if (h->opt[PQD_OPT_PRESCAN] < 0) wide_dict = false; }
-  // (and the variant of that walk with the smaller LDS footprint, unless a caller pinned the other)
-  const bool jump_dict = jump && !(fused_ran && h->opt[PQD_OPT_JUMP] < 0);
+  if (fused_ran) heavy = h->stream;
+  const bool jump_dict = jump;
   auto to_heavy = [&]() -> hipError_t {
     if (heavy == h->stream) return hipSuccess;
     hipError_t e = hipEventRecord(h->ev_ready, h->stream);
@@ -634,7 +632,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         const uint8_t *dptr = dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
         const int dn = dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
         HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, t_lo, t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
-                                   fused_ran, h->opt[PQD_OPT_SPLIT], heavy));
+                                   h->opt[PQD_OPT_SPLIT], heavy));
       }
       p = q;
     }

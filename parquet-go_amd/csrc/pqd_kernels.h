@@ -33,10 +33,10 @@ hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, c
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, int64_t *block_sums, hipStream_t stream);
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream);
 // dictionary indices -> gathered values, for the tiles [tile_lo, tile_hi) (the data pages that share one dictionary;
-// `dict` points at its first entry; dict_n < 0: they have none and their indices pass through).  split_mode 0 / 1 pins the mid-size dictionary variant; leftover: the one-pass kernel ran before (a launch of few, small workgroups)
+// `dict` points at its first entry; dict_n < 0: they have none and their indices pass through).  split_mode 0 / 1 pins the mid-size dictionary variant
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int tile_lo, int tile_hi,
                               int stage_bytes, const uint8_t *dict, int32_t dict_n, uint8_t *values_out, TileDesc *descs,
-                              int n_cu, bool leftover, int split_mode, hipStream_t stream);
+                              int n_cu, int split_mode, hipStream_t stream);
 
 // ---- k_plain.hip ----
 // dict_pages: device list of the call's dictionary pages (page indices)
