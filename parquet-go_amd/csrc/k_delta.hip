@@ -475,83 +475,105 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   DeltaBlock *tb = table + delta_table_base(pi);
   const uint8_t *in_last = c.in + ((c.in_len + 3) & ~(int64_t)3) - 4;             // last dword that may be read
 
+  // One round of the chain takes kSub x 64 blocks: every lane asks for the bytes of kSub guessed headers at once (the
+  // round trip to memory is what a round costs), then the sub-steps are confirmed in order; the first block of
+  // another length ends the round.
+  constexpr int kSub = 4;
   uint32_t pos = q, guess = 0;
   uint32_t b0 = 0;
   while (b0 < n_blocks) {
-    const uint32_t blk = b0 + (uint32_t)lane;
-    const uint64_t pj64 = (uint64_t)pos + (uint64_t)lane * guess;
-    const bool mine = blk < n_blocks && (lane == 0 || guess != 0) && pj64 + 5 <= end;
-    uint32_t size = 0, data_off = 0, widths = 0, dbytes = 0;
-    uint64_t md = 0;
-    bool good = false;
-    if (mine) {
-      const uint32_t pj = (uint32_t)pj64;
-      // 16 bytes at pj (aligned dwords, clamped at the end of the buffer: bytes past the stream are never looked at)
-      const uint8_t *a0 = src + pj;
-      const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
-      const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);
-      const uint32_t *wl = reinterpret_cast<const uint32_t *>(in_last);
-      uint32_t dw[5];
+    uint32_t dw[kSub][5];
+    bool mine_s[kSub];
+    uint64_t pj_s[kSub];
 #pragma unroll
-      for (int i = 0; i < 5; i++) dw[i] = *(w0 + i <= wl ? w0 + i : wl);
-      uint32_t x[4];
+    for (int s = 0; s < kSub; s++) {
+      const uint32_t blk = b0 + 64u * (uint32_t)s + (uint32_t)lane;
+      pj_s[s] = (uint64_t)pos + (uint64_t)(64u * (uint32_t)s + (uint32_t)lane) * guess;
+      mine_s[s] = blk < n_blocks && ((s == 0 && lane == 0) || guess != 0) && pj_s[s] + 5 <= end;
+      if (mine_s[s]) {
+        // 16 bytes at pj (aligned dwords, clamped at the end of the buffer: bytes past the stream are never looked at)
+        const uint8_t *a0 = src + (uint32_t)pj_s[s];
+        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
+        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);
+        const uint32_t *wl = reinterpret_cast<const uint32_t *>(in_last);
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], al * 8u);
-      // minimum delta: a varint of at most 10 bytes
-      uint32_t hl = 0, shift = 0;
-      bool closed = false;
-#pragma unroll
-      for (int i = 0; i < 10; i++) {
-        if (!closed) {
-          const uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-          hl++;
-          if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
-          shift += 7;
-          closed = (b & 0x80u) == 0;
-        }
-      }
-      if (closed && (uint64_t)pj + hl + 4 <= end) {
-        const uint64_t x64lo = ((uint64_t)x[1] << 32) | x[0], x64hi = ((uint64_t)x[3] << 32) | x[2];
-        const uint32_t wb = hl < 8 ? (uint32_t)((x64lo >> (8u * hl)) | (hl ? x64hi << (64u - 8u * hl) : 0ull)) : (uint32_t)(x64hi >> (8u * (hl - 8u)));
-        // miniblocks the stream still needs at this block (encodingread.go:372: reading stops with the count)
-        const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
-        const int need = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
-        uint32_t bytes = 0, wmax = 0;
-        widths = 0;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
-          if (m < need) { bytes += 4u * wm; widths |= wm << (8 * m); wmax = wm > wmax ? wm : wmax; }
-        }
-        data_off = pj + hl + 4u;
-        dbytes = bytes;
-        size = hl + 4u + bytes;
-        good = wmax <= 64u && (uint64_t)data_off + bytes <= end;
+        for (int i = 0; i < 5; i++) dw[s][i] = *(w0 + i <= wl ? w0 + i : wl);
       }
     }
-    // lane j sits at a true block start when every lane before it is good and as long as the guess
-    const uint64_t okm = __ballot(good && size == guess);
-    const uint64_t goodm = __ballot(good);
-    const int n_chain = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);   // lanes [0, n_chain) continue the chain at the guessed length
-    // the lane after them is at a true start too (its own length may differ)
-    int n_true = n_chain < 64 ? n_chain + 1 : 64;
-    if (guess == 0) n_true = 1;
-    if (b0 + (uint32_t)n_true > n_blocks) n_true = (int)(n_blocks - b0);
-    const uint64_t want = n_true >= 64 ? ~0ull : ((1ull << n_true) - 1);
-    if ((goodm & want) != want) return -1;       // a block the fast path does not take
-    if (lane < n_true) {
-      tb[blk] = DeltaBlock{data_off, widths, md};
-      // the byte range of the unit the block belongs to
-      const uint32_t ublocks = 1u << ushift;
-      if ((blk & (ublocks - 1u)) == 0u) pu[blk >> ushift].win_start = data_off;
-      if ((blk & (ublocks - 1u)) == ublocks - 1u || blk + 1u == n_blocks) pu[blk >> ushift].win_end = data_off + dbytes;
+    bool go_on = true;
+#pragma unroll
+    for (int s = 0; s < kSub; s++) {
+      if (!go_on) break;
+      const uint32_t blk = b0 + (uint32_t)lane;
+      const uint64_t pj64 = pj_s[s];
+      const bool mine = mine_s[s];
+      uint32_t size = 0, data_off = 0, widths = 0, dbytes = 0;
+      uint64_t md = 0;
+      bool good = false;
+      if (mine) {
+        const uint32_t pj = (uint32_t)pj64;
+        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(src + pj) & 3u);
+        uint32_t x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[s][i + 1], dw[s][i], al * 8u);
+        // minimum delta: a varint of at most 10 bytes
+        uint32_t hl = 0, shift = 0;
+        bool closed = false;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+          if (!closed) {
+            const uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            hl++;
+            if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
+            shift += 7;
+            closed = (b & 0x80u) == 0;
+          }
+        }
+        if (closed && (uint64_t)pj + hl + 4 <= end) {
+          const uint64_t x64lo = ((uint64_t)x[1] << 32) | x[0], x64hi = ((uint64_t)x[3] << 32) | x[2];
+          const uint32_t wb = hl < 8 ? (uint32_t)((x64lo >> (8u * hl)) | (hl ? x64hi << (64u - 8u * hl) : 0ull)) : (uint32_t)(x64hi >> (8u * (hl - 8u)));
+          // miniblocks the stream still needs at this block (encodingread.go:372: reading stops with the count)
+          const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
+          const int need = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
+          uint32_t bytes = 0, wmax = 0;
+          widths = 0;
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
+            if (m < need) { bytes += 4u * wm; widths |= wm << (8 * m); wmax = wm > wmax ? wm : wmax; }
+          }
+          data_off = pj + hl + 4u;
+          dbytes = bytes;
+          size = hl + 4u + bytes;
+          good = wmax <= 64u && (uint64_t)data_off + bytes <= end;
+        }
+      }
+      // lane j sits at a true block start when every lane before it is good and as long as the guess
+      const uint64_t okm = __ballot(good && size == guess);
+      const uint64_t goodm = __ballot(good);
+      const int n_chain = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);   // lanes [0, n_chain) continue the chain at the guessed length
+      // the lane after them is at a true start too (its own length may differ)
+      int n_true = n_chain < 64 ? n_chain + 1 : 64;
+      if (guess == 0) n_true = 1;
+      if (b0 + (uint32_t)n_true > n_blocks) n_true = (int)(n_blocks - b0);
+      const uint64_t want = n_true >= 64 ? ~0ull : ((1ull << n_true) - 1);
+      if ((goodm & want) != want) return -1;       // a block the fast path does not take
+      if (lane < n_true) {
+        tb[blk] = DeltaBlock{data_off, widths, md};
+        // the byte range of the unit the block belongs to
+        const uint32_t ublocks = 1u << ushift;
+        if ((blk & (ublocks - 1u)) == 0u) pu[blk >> ushift].win_start = data_off;
+        if ((blk & (ublocks - 1u)) == ublocks - 1u || blk + 1u == n_blocks) pu[blk >> ushift].win_end = data_off + dbytes;
+      }
+      const int last = n_true - 1;
+      const uint32_t pos_last = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)pj64), last);
+      const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)size, last);
+      pos = pos_last + size_last;
+      // the next sub-step was guessed right when all 64 lanes continued the chain (its first lane then sits at pos)
+      go_on = n_chain == 64 && n_true == 64 && guess != 0 && size_last == guess && b0 + 64u < n_blocks;
+      guess = size_last;
+      b0 += (uint32_t)n_true;
     }
-    const int last = n_true - 1;
-    const uint32_t pos_last = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)pj64), last);
-    const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)size, last);
-    pos = pos_last + size_last;
-    guess = size_last;
-    b0 += (uint32_t)n_true;
   }
   if (lane == 0) {
     tb[n_blocks] = DeltaBlock{0u, 0u, hdr[3]};
