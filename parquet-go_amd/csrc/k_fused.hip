@@ -393,12 +393,20 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
     if (lane == 0) { L->n = n_list; L->items = items; L->flags = ((fin && cg == 0) ? 1u : 0u) | (bail ? 2u : 0u); }
   };
 
+  // The barrier of a step: what the stages hand each other is in LDS, so a wavefront waits for its LDS operations only
+  // - the values it stored (and the dictionary entries it asked memory for) stay in flight across the barrier.  The
+  // walking wavefront also waits for the window it asked for (loads that write LDS count as memory operations).
+  auto step_barrier = [&]() {
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
   // the walk is the one serial chain of the page: its wavefront goes first whenever it has an instruction ready
   if (wave == 0) { __builtin_amdgcn_s_setprio(3); hop_step(&s_pos[0]); }
-  __syncthreads();
+  step_barrier();
   if (wave == 0) hop_step(&s_pos[1]);
   else if (wave == 1) make_list(&s_pos[0], &lists[0]);
-  __syncthreads();
+  step_barrier();
 
   bool bad_index = false;
   bool left = false;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) void k_page_fused(ChunkCtx c, const T *__r
         default: break;
       }
     }
-    __syncthreads();
+    step_barrier();
     if (fl & 1u) break;
   }
 
