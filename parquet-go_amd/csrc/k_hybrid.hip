@@ -822,7 +822,8 @@ constexpr int kDirectMaxLen = 64 * 1024;
 template <typename T, bool kLevels>
 __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
                                                         int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
-  // One round takes 1024 runs, four consecutive runs per thread.  The bytes of the stream come into LDS in 16-byte
+  // One round takes 1536 runs, six consecutive runs per thread (a page of the reference's writer - 8 KiB, about 1400
+  // runs - is one round).  The bytes of the stream come into LDS in 16-byte
   // pieces, 8 KiB at a time (a page of the reference's writer fits whole); every thread parses its runs and asks for
   // their dictionary entries together; a scan of the counts gives the runs their places, and the values go out by
   // position - four consecutive values per thread, the run that covers the first of them found by bisection over
@@ -830,7 +831,8 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   // a header of another shape anywhere, or too few values, and the stream is left to the general path, which writes
   // the same places again.
   constexpr int kWin = 8192;
-  constexpr int kRound = 1024;
+  constexpr int kPer = 6;                  // runs per thread and round
+  constexpr int kRound = 256 * kPer;
   __shared__ uint4 s_in4[kWin / 16 + 1];
   __shared__ uint32_t s_start[kRound + 1];
   __shared__ T s_val[kRound];
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
       win_al = (uint32_t)(reinterpret_cast<uintptr_t>(r0) & 15u);
       const int fit = (int)(((uint32_t)kWin - win_al) / stride);
       win_first = k0;
-      win_runs = n_runs - k0 < fit ? n_runs - k0 : fit;      // (fit >= 1024: a round always fits)
+      win_runs = n_runs - k0 < fit ? n_runs - k0 : fit;      // (fit >= kRound: a round always fits)
       const uint32_t need = win_al + (uint32_t)win_runs * stride;
 #pragma unroll
       for (int j = 0; j < kWin / 16 / 256; j++) {
@@ -885,11 +887,11 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
       }
       __syncthreads();
     }
-    // ---- four runs per thread ----
-    uint32_t n[4], val[4], mine = 0;
+    // ---- kPer runs per thread ----
+    uint32_t n[kPer], val[kPer], mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int kr = 4 * tid + j;
+    for (int j = 0; j < kPer; j++) {
+      const int kr = kPer * tid + j;
       n[j] = 0; val[j] = 0;
       if (kr < in_round) {
         const uint32_t bo = win_al + (uint32_t)(k0 - win_first + kr) * stride;
@@ -901,9 +903,9 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
       }
       mine += n[j];
     }
-    T v[4];
+    T v[kPer];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < kPer; j++) {
       if (kLevels) {
         v[j] = (T)val[j];
       } else {
@@ -925,13 +927,13 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
     if (carry < (uint32_t)cnt) {
       uint32_t start = before + incl - mine;           // place of the thread's first run inside the round
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < kPer; j++) {
         if (kLevels && n[j] > 0 && carry + start < (uint32_t)cnt) {
           const uint32_t end = carry + start + n[j] < (uint32_t)cnt ? start + n[j] : (uint32_t)cnt - carry;
           if (is_def ? val[j] != flag_val : val[j] == flag_val) n_flag += (int)(end - start);
         }
-        s_start[4 * tid + j] = start;
-        s_val[4 * tid + j] = v[j];
+        s_start[kPer * tid + j] = start;
+        s_val[kPer * tid + j] = v[j];
         start += n[j];
       }
       __syncthreads();
