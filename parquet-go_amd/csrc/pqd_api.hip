@@ -100,10 +100,34 @@ struct HostBuf {
     cap = want;
     return PQD_OK;
   }
+  // grows like ensure() and keeps the first `keep` bytes
+  int ensure_keep(size_t n, size_t keep) {
+    if (n <= cap) return PQD_OK;
+    if (pageable || keep == 0 || !p) return ensure(n);
+    void *old = p;
+    p = nullptr;
+    const size_t old_cap = cap;
+    cap = 0;
+    const int rc = ensure(std::max(n, old_cap + old_cap / 2));
+    if (rc == PQD_OK) std::memcpy(p, old, std::min(keep, old_cap));
+    (void)hipHostFree(old);
+    return rc;
+  }
   void release() {
     if (p) { if (pageable) std::free(p); else (void)hipHostFree(p); }
     p = nullptr; cap = 0;
   }
+};
+
+// A typed stretch of a host block (the tables of a call are built where they are uploaded from).
+template <class V>
+struct HostSpan {
+  V *p = nullptr;
+  size_t n = 0;
+  V &operator[](size_t i) const { return p[i]; }
+  V *data() const { return p; }
+  size_t size() const { return n; }
+  V &back() const { return p[n - 1]; }
 };
 
 struct KernelEvent {
@@ -160,10 +184,8 @@ struct pqd_handle {
   int stage_next = 0;
 
   // description of the last decode call
-  std::vector<PageIn> h_pages;
+  HostSpan<PageIn> h_pages;        // inside stage_meta: valid until the handle's next call
   std::vector<int32_t> h_dict_pages;
-  std::vector<StreamSeed> h_seeds;
-  std::vector<int32_t> h_tp_levels, h_tp_dict, h_tp_plain;
   pqd_column_desc col{};
   int n_pages = 0, nd = 0;
   int64_t total_slots = 0;
@@ -323,8 +345,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   if (is_bytes && span > ((size_t)1 << 40)) return fail_arg("BYTE_ARRAY chunks of one call must lie within 1 TiB of device address space");
   if (is_bytes && h->no_alloc) return fail_arg("BYTE_ARRAY columns need the allocating entry points");
 
-  // ---- host-side page table; the dictionary in effect follows the page order of each chunk ----
-  h->h_pages.resize((size_t)n_pages);
+  // ---- host-side page table, built in the block it is uploaded from; the dictionary in effect follows the page
+  //      order of each chunk ----
+  int rc;
+  const size_t pages_bytes = sizeof(PageIn) * (size_t)n_pages;
+  if ((rc = h->stage_meta.ensure(pages_bytes + 256))) return rc;
+  h->h_pages = HostSpan<PageIn>{static_cast<PageIn *>(h->stage_meta.p), (size_t)n_pages};
   h->h_dict_pages.clear();
   int nd = 0;
   int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0;
@@ -383,11 +409,24 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // ---- meta block: pages | seeds | tile prefixes | tile -> stream maps | dictionary pages; then, device only,
   //      state | streams ----
   const size_t n_streams = (size_t)3 * nd;
-  // (the host arrays belong to the handle: allocating and clearing megabytes per call costs more than filling them)
-  std::vector<StreamSeed> &h_seeds = h->h_seeds;
-  std::vector<int32_t> &tp_levels = h->h_tp_levels, &tp_dict = h->h_tp_dict, &tp_plain = h->h_tp_plain;
-  h_seeds.resize(n_streams);
-  tp_levels.resize(2 * (size_t)nd + 1); tp_dict.resize((size_t)nd + 1); tp_plain.resize((size_t)nd + 1);
+  const size_t off_pages = 0;
+  const size_t off_seeds = align_up(off_pages + pages_bytes, 256);
+  const size_t off_tp_lv = align_up(off_seeds + sizeof(StreamSeed) * n_streams, 256);
+  const size_t off_tp_dc = align_up(off_tp_lv + 4 * (2 * (size_t)nd + 1), 256);
+  const size_t off_tp_pl = align_up(off_tp_dc + 4 * ((size_t)nd + 1), 256);
+  const size_t off_ts_lv = align_up(off_tp_pl + 4 * ((size_t)nd + 1), 256);
+  if ((rc = h->stage_meta.ensure_keep(off_ts_lv, pages_bytes))) return rc;
+  HostSpan<StreamSeed> h_seeds;
+  HostSpan<int32_t> tp_levels, tp_dict, tp_plain;
+  auto place_tables = [&] {      // (again after the block has grown)
+    uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
+    h->h_pages = HostSpan<PageIn>{reinterpret_cast<PageIn *>(m + off_pages), (size_t)n_pages};
+    h_seeds = HostSpan<StreamSeed>{reinterpret_cast<StreamSeed *>(m + off_seeds), n_streams};
+    tp_levels = HostSpan<int32_t>{reinterpret_cast<int32_t *>(m + off_tp_lv), 2 * (size_t)nd + 1};
+    tp_dict = HostSpan<int32_t>{reinterpret_cast<int32_t *>(m + off_tp_dc), (size_t)nd + 1};
+    tp_plain = HostSpan<int32_t>{reinterpret_cast<int32_t *>(m + off_tp_pl), (size_t)nd + 1};
+  };
+  place_tables();
   int64_t run_total = 0, tile_total = 0;
   {
     int64_t t_lv = 0, t_dc = 0, t_pl = 0;
@@ -435,12 +474,6 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     tp_plain[(size_t)nd] = (int32_t)t_pl;
   }
   auto t_seeds = tnow();
-  const size_t off_pages = 0;
-  const size_t off_seeds = align_up(off_pages + sizeof(PageIn) * (size_t)n_pages, 256);
-  const size_t off_tp_lv = align_up(off_seeds + sizeof(StreamSeed) * n_streams, 256);
-  const size_t off_tp_dc = align_up(off_tp_lv + 4 * tp_levels.size(), 256);
-  const size_t off_tp_pl = align_up(off_tp_dc + 4 * tp_dict.size(), 256);
-  const size_t off_ts_lv = align_up(off_tp_pl + 4 * tp_plain.size(), 256);
   const size_t off_ts_dc = align_up(off_ts_lv + 4 * (size_t)tp_levels.back(), 256);
   const size_t off_dictp = align_up(off_ts_dc + 4 * (size_t)tp_dict.back(), 256);
   const size_t upload_bytes = align_up(off_dictp + 4 * (size_t)n_dict, 256);
@@ -455,8 +488,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     for (DevBuf *b : h->all_bufs_) if (b->arena) { b->p = nullptr; b->cap = 0; }
     if (h->small.arena) h->small.arena->used = 0;
   }
-  int rc;
-  if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure(upload_bytes))) return rc;
+  if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure_keep(upload_bytes, off_ts_lv))) return rc;
+  place_tables();
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
   if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
@@ -513,11 +546,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   h->bytes_len = 0;
   {
     uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
-    if (n_pages) std::memcpy(m + off_pages, h->h_pages.data(), sizeof(PageIn) * (size_t)n_pages);
-    if (n_streams) std::memcpy(m + off_seeds, h_seeds.data(), sizeof(StreamSeed) * n_streams);
-    std::memcpy(m + off_tp_lv, tp_levels.data(), 4 * tp_levels.size());
-    std::memcpy(m + off_tp_dc, tp_dict.data(), 4 * tp_dict.size());
-    std::memcpy(m + off_tp_pl, tp_plain.data(), 4 * tp_plain.size());
+    // (page table, seeds and tile prefixes were built in place)
     if (n_dict) std::memcpy(m + off_dictp, h->h_dict_pages.data(), 4 * (size_t)n_dict);
     // tile -> stream maps of the two hybrid expansions, written in place
     int32_t *ts_lv = reinterpret_cast<int32_t *>(m + off_ts_lv), *ts_dc = reinterpret_cast<int32_t *>(m + off_ts_dc);
