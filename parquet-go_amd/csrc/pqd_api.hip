@@ -353,7 +353,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   h->h_pages = HostSpan<PageIn>{static_cast<PageIn *>(h->stage_meta.p), (size_t)n_pages};
   h->h_dict_pages.clear();
   int nd = 0;
-  int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0;
+  int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0, lv_runs = 0, lv_tiles = 0;
   int host_status = PQD_OK, host_bad = -1;
   bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_rle = false;
   bool any_dlba = false, any_dba = false;
@@ -376,6 +376,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         pi.data_idx = nd++;
         data_bytes += d.length;
         if (d.num_values > 0) slots += d.num_values;
+        {   // what a level stream of the page takes in the run table and the tile table
+          const int64_t nv = d.num_values > 0 ? d.num_values : 0;
+          lv_runs += std::min<int64_t>(nv, d.length) + 2;
+          lv_tiles += (nv + kTile - 1) / kTile;
+        }
         if (cur_dict >= 0) {
           const PageIn &dp = h->h_pages[(size_t)cur_dict];
           pi.dict_page = cur_dict; pi.dict_n = dp.dict_n; pi.dict_off = dp.dict_off;
@@ -427,48 +432,62 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     tp_plain = HostSpan<int32_t>{reinterpret_cast<int32_t *>(m + off_tp_pl), (size_t)nd + 1};
   };
   place_tables();
+  // Run-table ranges, tile-table ranges and tile prefixes of the three groups of streams (repetition levels,
+  // definition levels, values), one pass over the pages: the level groups take the same room each (added up with the
+  // page table), so every group's base is known beforehand.  A group no stream of which is decoded has empty run
+  // ranges and one (end) entry per stream in the tile table.
   int64_t run_total = 0, tile_total = 0;
   {
-    int64_t t_lv = 0, t_dc = 0, t_pl = 0;
-    for (int g = 0; g < 3; g++) {
-      const bool group_wanted = (g == 0 && col->max_rep > 0) || (g == 1 && col->max_def > 0) || (g == 2 && !levels_only);
-      if (!group_wanted) {
-        // a group no stream of which is decoded: empty run ranges, one (end) entry in the tile table each
-        StreamSeed *sg = h_seeds.data() + (size_t)g * nd;
-        for (int d = 0; d < nd; d++) {
-          sg[d].run_base = run_total; sg[d].run_cap = 0; sg[d].tile_base = (int32_t)(tile_total + d);
-          if (g < 2) tp_levels[(size_t)g * nd + d] = (int32_t)t_lv;
-          else { tp_dict[(size_t)d] = (int32_t)t_dc; tp_plain[(size_t)d] = (int32_t)t_pl; }
+    const bool wanted[3] = {col->max_rep > 0, col->max_def > 0, !levels_only};
+    int64_t run_base[3], tile_base[3], tlv_base[2];
+    int64_t t_lv = 0;
+    for (int g = 0; g < 2; g++) {
+      run_base[g] = run_total; tile_base[g] = tile_total; tlv_base[g] = t_lv;
+      run_total += wanted[g] ? lv_runs : 0;
+      tile_total += wanted[g] ? lv_tiles + nd : nd;
+      t_lv += wanted[g] ? lv_tiles : 0;
+    }
+    run_base[2] = run_total; tile_base[2] = tile_total;
+    if (tile_total > 0x7FFFFFF0ll || t_lv > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
+    int64_t acc_runs = 0, acc_tiles = 0, v_runs = 0, v_tiles = 0, t_dc = 0, t_pl = 0;
+    StreamSeed *s0 = h_seeds.data(), *s1 = s0 + nd, *s2 = s1 + nd;
+    for (int p = 0; p < n_pages; p++) {
+      const PageIn &pi = h->h_pages[(size_t)p];
+      if (pi.data_idx < 0) continue;
+      const int d = pi.data_idx;
+      const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
+      const int64_t tiles = (nv + kTile - 1) / kTile;
+      const int64_t rcap = std::min<int64_t>(nv, pi.body_len) + 2;
+      StreamSeed *const sg[2] = {s0 + d, s1 + d};
+      for (int g = 0; g < 2; g++) {
+        if (wanted[g]) {
+          sg[g]->run_base = run_base[g] + acc_runs; sg[g]->run_cap = (int32_t)rcap; sg[g]->tile_base = (int32_t)(tile_base[g] + acc_tiles + d);
+          tp_levels[(size_t)g * nd + d] = (int32_t)(tlv_base[g] + acc_tiles);
+        } else {
+          sg[g]->run_base = run_base[g]; sg[g]->run_cap = 0; sg[g]->tile_base = (int32_t)(tile_base[g] + d);
+          tp_levels[(size_t)g * nd + d] = (int32_t)tlv_base[g];
         }
-        tile_total += nd;
-        if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
-        continue;
       }
-      for (int p = 0; p < n_pages; p++) {
-        const PageIn &pi = h->h_pages[(size_t)p];
-        if (pi.data_idx < 0) continue;
-        const int d = pi.data_idx;
-        StreamSeed &s = h_seeds[(size_t)g * nd + d];
-        const int64_t nv = pi.num_values > 0 ? pi.num_values : 0;
-        const bool want = g < 2 || is_dict_enc(pi.encoding) || (pi.encoding == PQD_ENC_RLE && rle_typed && !is_bytes);
-        const int64_t tiles = want ? (nv + kTile - 1) / kTile : 0;
-        const int64_t rcap = want ? std::min<int64_t>(nv, pi.body_len) + 2 : 0;
-        s.run_base = run_total; s.run_cap = (int32_t)rcap; s.tile_base = (int32_t)tile_total;
-        run_total += rcap;
-        tile_total += tiles + 1;
-        if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
-        if (g < 2) { tp_levels[(size_t)g * nd + d] = (int32_t)t_lv; t_lv += tiles; }
-        else {
-          tp_dict[(size_t)d] = (int32_t)t_dc; t_dc += tiles;
-          tp_plain[(size_t)d] = (int32_t)t_pl;
-          if (pi.encoding == PQD_ENC_PLAIN || (pi.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
-            const int64_t units = col->physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)esz;
-            t_pl += (units + kPlainTile - 1) / kPlainTile;
-          }
+      acc_runs += rcap; acc_tiles += tiles;
+      if (wanted[2]) {
+        const bool want = is_dict_enc(pi.encoding) || (pi.encoding == PQD_ENC_RLE && rle_typed && !is_bytes);
+        s2[d].run_base = run_base[2] + v_runs; s2[d].run_cap = (int32_t)(want ? rcap : 0); s2[d].tile_base = (int32_t)(tile_base[2] + v_tiles + d);
+        tp_dict[(size_t)d] = (int32_t)t_dc;
+        tp_plain[(size_t)d] = (int32_t)t_pl;
+        if (want) { v_runs += rcap; v_tiles += tiles; t_dc += tiles; }
+        if (pi.encoding == PQD_ENC_PLAIN || (pi.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
+          const int64_t units = col->physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)esz;
+          t_pl += (units + kPlainTile - 1) / kPlainTile;
         }
-        if (t_lv > 0x7FFFFFF0ll || t_dc > 0x7FFFFFF0ll || t_pl > 0x7FFFFFF0ll) return fail_arg("chunk too large (tiles)");
+        if (tile_base[2] + v_tiles + d > 0x7FFFFFF0ll || t_pl > 0x7FFFFFF0ll) return fail_arg("chunk too large (tiles)");
+      } else {
+        s2[d].run_base = run_base[2]; s2[d].run_cap = 0; s2[d].tile_base = (int32_t)(tile_base[2] + d);
+        tp_dict[(size_t)d] = 0; tp_plain[(size_t)d] = 0;
       }
     }
+    run_total += v_runs;
+    tile_total += v_tiles + nd;
+    if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
     tp_levels[2 * (size_t)nd] = (int32_t)t_lv;
     tp_dict[(size_t)nd] = (int32_t)t_dc;
     tp_plain[(size_t)nd] = (int32_t)t_pl;
