@@ -481,6 +481,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   constexpr int kSub = 4;
   uint32_t pos = q, guess = 0;
   uint32_t b0 = 0;
+  int n_sub = 1;                 // guesses per round: kSub while the lengths hold, one after a round that met another length
   while (b0 < n_blocks) {
     uint32_t dw[kSub][5];
     bool mine_s[kSub];
@@ -489,7 +490,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     for (int s = 0; s < kSub; s++) {
       const uint32_t blk = b0 + 64u * (uint32_t)s + (uint32_t)lane;
       pj_s[s] = (uint64_t)pos + (uint64_t)(64u * (uint32_t)s + (uint32_t)lane) * guess;
-      mine_s[s] = blk < n_blocks && ((s == 0 && lane == 0) || guess != 0) && pj_s[s] + 5 <= end;
+      mine_s[s] = s < n_sub && blk < n_blocks && ((s == 0 && lane == 0) || guess != 0) && pj_s[s] + 5 <= end;
       if (mine_s[s]) {
         // 16 bytes at pj (aligned dwords, clamped at the end of the buffer: bytes past the stream are never looked at)
         const uint8_t *a0 = src + (uint32_t)pj_s[s];
@@ -500,10 +501,10 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
         for (int i = 0; i < 5; i++) dw[s][i] = *(w0 + i <= wl ? w0 + i : wl);
       }
     }
-    bool go_on = true;
+    bool go_on = true, held = false;
 #pragma unroll
     for (int s = 0; s < kSub; s++) {
-      if (!go_on) break;
+      if (!go_on || s >= n_sub) break;
       const uint32_t blk = b0 + (uint32_t)lane;
       const uint64_t pj64 = pj_s[s];
       const bool mine = mine_s[s];
@@ -570,10 +571,12 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
       const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)size, last);
       pos = pos_last + size_last;
       // the next sub-step was guessed right when all 64 lanes continued the chain (its first lane then sits at pos)
-      go_on = n_chain == 64 && n_true == 64 && guess != 0 && size_last == guess && b0 + 64u < n_blocks;
+      held = n_chain == 64 && n_true == 64 && guess != 0 && size_last == guess;
+      go_on = held && b0 + 64u < n_blocks;
       guess = size_last;
       b0 += (uint32_t)n_true;
     }
+    n_sub = held ? kSub : 1;
   }
   if (lane == 0) {
     tb[n_blocks] = DeltaBlock{0u, 0u, hdr[3]};

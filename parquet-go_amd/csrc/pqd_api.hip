@@ -643,8 +643,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
   if (!heavy || !h->ev_ready || !h->ev_done) heavy = h->stream;
-  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream)
+  // (after the one-pass kernel the tile expansion has little or nothing left to do: it stays on the handle's stream,
+  //  and for a mid-size dictionary it takes the plain gather - the variant that keeps the dictionary's head in LDS is
+  //  made of workgroups that need a CU to themselves, and on a busy GPU a launch that finds nothing left would wait for
+  //  CUs to drain before it could return)
   const bool fused_ran = fused && any_dict_enc && (is_bytes || esz == 4 || esz == 8);
+  const int split_mode = fused_ran && h->opt[PQD_OPT_SPLIT] < 0 ? 0 : h->opt[PQD_OPT_SPLIT];
   if (fused_ran) heavy = h->stream;
   const bool jump_dict = jump;
   auto to_heavy = [&]() -> hipError_t {
@@ -680,7 +684,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         const uint8_t *dptr = dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
         const int dn = dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
         HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, t_lo, t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
-                                   h->opt[PQD_OPT_SPLIT], heavy));
+                                   split_mode, heavy));
       }
       p = q;
     }
