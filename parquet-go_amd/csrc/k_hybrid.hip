@@ -904,13 +904,14 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
       mine += n[j];
     }
     T v[kPer];
+    uint32_t oob = 0;       // runs whose index the dictionary does not hold
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
       if (kLevels) {
         v[j] = (T)val[j];
       } else {
         uint32_t idx = val[j];
-        if (n[j] > 0 && idx >= (uint32_t)dict_n) { bad_index = 1; idx = 0; }   // dict.Values[index] out of range (layout/page.go:139-164)
+        if (n[j] > 0 && idx >= (uint32_t)dict_n) { oob |= 1u << j; idx = 0; }
         v[j] = (n[j] > 0 && dict_n > 0) ? dict[idx] : T(0);
       }
     }
@@ -932,6 +933,9 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
           const uint32_t end = carry + start + n[j] < (uint32_t)cnt ? start + n[j] : (uint32_t)cnt - carry;
           if (is_def ? val[j] != flag_val : val[j] == flag_val) n_flag += (int)(end - start);
         }
+        // dict.Values[index] out of range (layout/page.go:139-164) - for a run the page's count reaches: the reference
+        // stops reading the stream once it has the values it needs
+        if (((oob >> j) & 1u) && carry + start < (uint32_t)cnt) bad_index = 1;
         s_start[kPer * tid + j] = start;
         s_val[kPer * tid + j] = v[j];
         start += n[j];

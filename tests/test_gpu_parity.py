@@ -148,6 +148,35 @@ def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
 
 
 @pytest.mark.parametrize("direct", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_index_out_of_range_in_a_run_the_page_never_reaches(dec, oracle, direct, fused):
+    # ReadRLEBitPackedHybrid stops reading once it has the page's values (encodingread.go:240-268): an index beyond
+    # the dictionary in a run behind them is never looked up; in the run that the count ends in, it is
+    dec.set_option(1, int(direct))           # PQD_OPT_DIRECT_RLE
+    dec.set_option(7, int(fused))            # PQD_OPT_FUSED
+    rng = np.random.default_rng(4711)
+    nd = 50
+    for w in (8, 32):
+        nb = (w + 7) // 8
+        run = lambda c, v: bytes([c << 1]) + int(v).to_bytes(4, "little")[:nb]
+        for last_ok in (True, False):
+            cb = pg.ChunkBuilder(gap=3)
+            cb.dict_page(rand_dict(rng, pg.INT32, nd), nd)
+            for n in (7, 300, 2048):
+                body, have = bytearray(), 0
+                while have + 5 < n:
+                    c = int(rng.integers(1, 4))
+                    body += run(c, rng.integers(0, nd)); have += c
+                # the run the count ends in, then runs nobody reads
+                body += run(n - have + 2, rng.integers(0, nd) if last_ok else nd + 3)
+                body += run(3, nd + 7) + run(1, 0xFFFFFFFF >> (32 - 8 * nb))
+                cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([w]) + bytes(body))
+            chunk, pages = cb.finish()
+            g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
+            assert (o.status == 0) == last_ok
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
 @pytest.mark.parametrize("ptype,w", [(pg.INT32, 32), (pg.INT64, 32), (pg.INT32, 9), (pg.DOUBLE, 1), (pg.BYTE_ARRAY, 32), (pg.INT96, 32),
                                      (pg.BYTE_ARRAY, 7)])
 def test_rle_only_pages_expanded_straight_from_the_page(dec, oracle, ptype, w, direct):
