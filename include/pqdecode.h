@@ -129,7 +129,7 @@ int pqd_set_profiling(pqd_handle *h, int on);
 
 /* Kernel-variant choices of a handle.  Results never depend on them; tests pin each variant with them.  value -1
  * returns a choice to the library.  New handles start from the environment (read once per process):
- * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_DELTA_BLOCKS=0|1. */
+ * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_DELTA_BLOCKS=0|1, PQD_FUSED=0|1. */
 enum {
   PQD_OPT_PRESCAN = 0,        /* run-header walk: 0 a wavefront per stream, 1 a workgroup per stream */
   PQD_OPT_DIRECT_RLE = 1,     /* 0 / 1: expansion of RLE-only pages straight from the page */

@@ -44,10 +44,12 @@ def pq():
     return pq
 
 
-def test_dictionary_chunk_equals_its_halves_and_the_oracle(pq, oracle):
+@pytest.mark.parametrize("w", [12, 1, 8, 20])
+def test_dictionary_chunk_equals_its_halves_and_the_oracle(pq, oracle, w):
+    # (w = 20: a dictionary of 64 Ki entries, larger than LDS; w = 1: two entries)
     import torch
-    n, page_values, w = 256 << 20, 1 << 20, 12
-    chunk, pages = pqgen.dict_chunk(0x5EED0102, n, w, 1 << w, page_values)
+    n, page_values = 256 << 20, 1 << 20
+    chunk, pages = pqgen.dict_chunk(0x5EED0102 + w, n, w, min(1 << w, 65536), page_values)
     dev = to_device(chunk)
     dec = pq.Decoder(0)
     dec.submit_device(dev.data_ptr(), chunk.size, pages, pq.INT32)
@@ -66,7 +68,7 @@ def test_dictionary_chunk_equals_its_halves_and_the_oracle(pq, oracle):
     assert torch.equal(full, torch.cat(parts))
     assert checksum(full) == checksum(torch.cat(parts))
     # sampled pages against the oracle
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + w)
     for k in sorted(rng.choice(np.arange(1, pages.size), 3, replace=False)):
         o = oracle.read_chunk(chunk, np.concatenate([pages[:1], pages[k:k + 1]]), oracle.INT32)
         assert o.status == 0
