@@ -434,6 +434,7 @@ struct DeltaWork {
 constexpr int kMaxUnitShift = 6, kMinUnitShift = 3;
 constexpr uint32_t kMaxUnitBlocks = 1u << kMaxUnitShift;
 constexpr int kMaxWinBytes = 13312;
+constexpr int kMinWinBytes = 2560;      // two blocks of the widest kind and the window's alignment
 
 __device__ __forceinline__ int64_t delta_table_base(const PageIn &pi) { return (pi.slot_base >> 7) + 3 * (int64_t)pi.data_idx; }
 __device__ __forceinline__ int64_t delta_unit_base(const PageIn &pi, int ushift) { return (pi.slot_base >> (7 + ushift)) + (int64_t)pi.data_idx; }
@@ -766,8 +767,8 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
     const bool fits = (uint32_t)lane >= bs && (uint32_t)lane < nb_here && data_end - a0 <= kWinBytes;
     const uint64_t fm = __ballot(fits) >> bs;
     uint32_t n = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
-    if (bs + n < nb_here) n &= ~1u;                 // steps take blocks in pairs
-    const uint32_t be = bs + n;                     // (n >= 2: two blocks of the widest kind are about 2 KiB)
+    if (bs + n < nb_here && n > 1u) n &= ~1u;       // steps take blocks in pairs
+    const uint32_t be = bs + n;                     // (n >= 1: a block of the widest kind - ten header bytes, 64-bit deltas - is 1038 bytes, and the window never has fewer than kMinWinBytes)
     const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)data_end, (int)(be - 1u));
     __syncthreads();                                // the window's previous readers are done
     fill_window(a0, end);
@@ -993,7 +994,7 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
       ushift = kMaxUnitShift;
       while (ushift > kMinUnitShift && block_bytes * (double)(1 << ushift) + 32.0 > (double)kMaxWinBytes) ushift--;
       win_bytes = ((int)(block_bytes * (double)(1 << ushift) * 1.01) + 64 + 511) / 512 * 512;
-      if (win_bytes < 2048) win_bytes = 2048;
+      if (win_bytes < kMinWinBytes) win_bytes = kMinWinBytes;
       if (win_bytes > kMaxWinBytes) win_bytes = kMaxWinBytes;
     }
     const size_t nb = (size_t)slots / 128 + 3 * (size_t)c.nd + 8, nu = ((size_t)slots >> (7 + kMinUnitShift)) + (size_t)c.nd + 8;

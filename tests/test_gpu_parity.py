@@ -545,6 +545,24 @@ def test_delta_block_parallel_and_wave_per_page_agree_with_the_oracle(dec, oracl
         check_same(dec, oracle, chunk, pp, pg.INT64)
 
 
+def test_delta_page_of_constant_blocks_with_a_few_of_the_widest_kind(dec, oracle):
+    # Pages that spend next to nothing per value (blocks of width 0: five bytes each) get the smallest window over a
+    # unit's packed bytes; the unit that holds blocks of the widest kind (ten-byte minimum delta, 64-bit deltas: 1038
+    # bytes each) is then decoded through a window that moves over its blocks - two such blocks must fit it.
+    rng = np.random.default_rng(20782028245)
+    cb = pg.ChunkBuilder(gap=7, lead=3)
+    info = np.iinfo(np.int64)
+    for n, at in ((58183, 74), (120000, 3), (30000, 130)):
+        d = np.full(n, 3, np.int64)
+        d[128 * at + 1:128 * at + 385] = rng.integers(info.min, info.max, 384)     # three such blocks next to each other
+        with np.errstate(over="ignore"):
+            vals = np.cumsum(d.astype(np.uint64)).view(np.int64)
+        cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, n, pg.delta_encode_fast(vals, np.int64))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT64)
+    assert o.status == 0
+
+
 def test_delta_reference_writer_and_other_geometries(dec, oracle):
     rng = np.random.default_rng(33)
     cb = pg.ChunkBuilder()
