@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void k_tile_desc(ExpandArgs a) {
   const int b_lo = (e0.x >> 31) ? (int)(e0.y + k0 * w) : tk.y;
   const int b_hi = tk1.y + (int)w + 1;
   d.org = b_lo - (int)((reinterpret_cast<uintptr_t>(c.in + d.in_off) + (uintptr_t)(uint32_t)b_lo) & 15u);
-  d.span = b_hi - d.org;
+  // (a tile deep inside a bit-packed run that the stream holds only the beginning of starts behind the stream's last
+  //  byte: it touches no bytes at all, and every value of it is the zero fill)
+  d.span = b_hi > d.org ? b_hi - d.org : 0;
   const bool in_lds = d.nr <= a.runs_cap + 2 && (d.nr + 1) * (int)sizeof(RunEntry) + ((d.span + 8 + 15) & ~15) <= a.pool_bytes && d.n_items <= a.mark_cap;
   // bit 3: the values are the unpacked numbers themselves (Encoding_RLE data pages, layout/page.go:657-667)
   // (also set for dictionary-encoded pages that have no dictionary page in front of them: the call fails for them

@@ -932,6 +932,34 @@ def test_truncated_bit_packed_run_is_zero_filled(dec, oracle):
     assert o.status == 0
 
 
+@pytest.mark.parametrize("w", [1, 8, 12])
+def test_one_long_bit_packed_run_cut_short_tiles_behind_the_last_byte(dec, oracle, w):
+    # One bit-packed run announces tens of thousands of values and the page ends a few hundred bytes into it: the
+    # tiles further on lie wholly behind the stream's last byte, and all their values are the zero fill
+    # (encodingread.go:188-191) - in the index stream of a dictionary page and in a definition-level stream alike.
+    rng = np.random.default_rng(1620 + w)
+    nd = min(1 << w, 300)
+    n = 20000
+    groups = 35334
+    for lead_runs in (0, 700):
+        cb = pg.ChunkBuilder(gap=3, lead=2)
+        cb.dict_page(rng.integers(-2**31, 2**31 - 1, nd, dtype=np.int32).tobytes(), nd)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, nd, n), w, rng))
+        head = pg.hybrid_encode(rng.integers(0, nd, lead_runs), w, rng, "rle") if lead_runs else b""
+        body = bytes([w]) + head + pg.varint((groups << 1) | 1) + pg.bitpack(rng.integers(0, nd, 512), w)[:509 * w // 8 + 1]
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, body)
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, nd, n), w, rng))
+        chunk, pages = cb.finish()
+        g, o = check_same(dec, oracle, chunk, pages, pg.INT32)
+        assert o.status == 0
+    # the same in a definition-level stream (v2 page: the level bytes are the run itself)
+    cb = pg.ChunkBuilder(gap=1)
+    runs = pg.varint((groups << 1) | 1) + pg.bitpack(rng.integers(0, 2, 512), 1)[:40]
+    cb.data_page_v2(pg.ENC_PLAIN, n, rng.integers(0, 256, 8 * n, dtype=np.uint8).tobytes(), b"", runs)
+    chunk, pages = cb.finish()
+    check_same(dec, oracle, chunk, pages, pg.INT64, 0, 1, 0)
+
+
 @pytest.mark.parametrize("w", [1, 5, 12, 20])
 def test_bit_packed_payload_cut_far_short(dec, oracle, w):
     # headers announce long bit-packed runs but the page ends after a fraction of the payload: everything the
