@@ -49,12 +49,16 @@ def test_oracle_survives_malformed_chunks(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,variant", [(20240, None), (777000, "wave"), (31337, "wide")])
+@pytest.mark.parametrize("seed,variant", [(20240, None), (777000, "wave"), (31337, "wide"), (162718, "poison")])
 def test_library_and_oracle_agree_on_malformed_chunks(oracle, seed, variant):
     import parquet_go_amd as pq
     dec = pq.Decoder(0)
     if variant:
         dec.set_option(pq.binding.OPT_PRESCAN, 1 if variant == "wide" else 0)   # both run-header walks see the malformed streams
+    if variant == "poison":
+        # every work and output buffer filled with 0xFF before each call: a kernel that reads what it (or a failed
+        # page) never wrote shows up as a difference (this seed holds a bit-packed run cut short many tiles early)
+        dec.set_option(pq.binding.OPT_POISON, 1)
     bad, refused, other_kind = [], 0, []
     for name, chunk, pages, ptype, tl, md, mr in fuzzcases.cases(300, seed):
         o = oracle.read_chunk(chunk, pages, ptype, tl, md, mr)
