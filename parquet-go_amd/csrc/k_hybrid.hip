@@ -69,6 +69,10 @@ __global__ void k_page_setup(ChunkCtx c) {
   // looks at the definition levels (layout/page.go:835-881): an error inside the repetition level runs comes first.
   int status = PQD_OK, def_status = PQD_OK;
   if (nv < 0) status = PQD_ERR_MALFORMED;
+  // a v2 page is cut into its sections before anything is read (layout/page.go:736-773): sections longer than the page
+  // are a slice out of range there, whatever the page's value count
+  if (pi.page_type == PQD_DATA_PAGE_V2 && (pi.rep_len < 0 || pi.def_len < 0 || (int64_t)pi.rep_len + pi.def_len > pi.body_len))
+    status = PQD_ERR_MALFORMED;
   if (status == PQD_OK && nv > 0) {  // with num_values == 0 ReadDataPageValues returns before reading anything
     if (pi.page_type == PQD_DATA_PAGE) {
       if (c.max_rep > 0) {
@@ -83,9 +87,7 @@ __global__ void k_page_setup(ChunkCtx c) {
       }
     } else {  // DATA_PAGE_V2
       int64_t rll = pi.rep_len, dll = pi.def_len;
-      if (rll < 0 || dll < 0 || rll + dll > pi.body_len) {
-        status = PQD_ERR_MALFORMED;
-      } else {
+      {
         // The reference re-frames a non-empty section with a synthetic length prefix and then reads prefixed blocks
         // only for the levels the column has (layout/page.go:760-773, :835-881): a section that is empty although
         // the column has that level, or present although it has not, makes it read the next section (or the values)

@@ -932,6 +932,25 @@ def test_truncated_bit_packed_run_is_zero_filled(dec, oracle):
     assert o.status == 0
 
 
+def test_v2_page_without_values_whose_level_sections_outgrow_it(dec, oracle):
+    # ReadPage cuts a v2 page into its sections before it reads anything (layout/page.go:736-773): level sections
+    # longer than the page are a slice out of range even when the page announces no values
+    rng = np.random.default_rng(343099)
+    for nv, rep_len, def_len, body_len, ok in ((0, 2, 2, 2, False), (0, 2, 2, 4, True), (0, 0, 9, 3, False), (1, 2, 2, 3, False)):
+        cb = pg.ChunkBuilder(gap=2)
+        cb.dict_page(rng.integers(0, 256, 8, dtype=np.uint8).tobytes(), 2)
+        cb.data_page_v2(pg.ENC_RLE_DICTIONARY, nv, b"", b"", b"")
+        cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 100, pg.dict_indices_body(rng.integers(0, 2, 60), 1, rng),
+                        pg.level_block_v1(np.concatenate([[0], rng.integers(0, 2, 99)]), 1, rng),
+                        pg.level_block_v1(np.array([2] * 60 + [1] * 40), 2, rng))
+        chunk, pages = cb.finish()
+        chunk = bytearray(chunk)
+        pages = pages.copy()
+        pages["rep_len"][1], pages["def_len"][1], pages["length"][1] = rep_len, def_len, body_len
+        g, o = check_same(dec, oracle, bytes(chunk), pages, pg.INT32, 0, 2, 1)
+        assert (o.status == 0) == ok, (nv, rep_len, def_len, body_len, o.status)
+
+
 @pytest.mark.parametrize("w", [1, 8, 12])
 def test_one_long_bit_packed_run_cut_short_tiles_behind_the_last_byte(dec, oracle, w):
     # One bit-packed run announces tens of thousands of values and the page ends a few hundred bytes into it: the
