@@ -229,8 +229,10 @@ int pqd_decode_chunks_device(pqd_handle *h, int32_t n_chunks, const void *const 
                              const pqd_page_desc *pages, const int32_t *pages_per_chunk, const pqd_column_desc *col,
                              int32_t flags);
 
-/* pqd_decode_chunk_device for callers that cannot allocate (code under HIP graph capture rules, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  No handle: the work space is a fixed
+/* pqd_decode_chunk_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb a graph capture going on elsewhere in the process by allocating).  The call itself is
+ * synchronous - it waits for `stream` and copies the totals back - so it cannot be made while `stream` is being
+ * captured.  It has no counterpart in the reference.  No handle: the work space is a fixed
  * array of 32 MiB that every GPU the library runs on holds from load to process end, the outputs are the caller's
  * device buffers, and the call makes no hipMalloc / hipFree / hipHostMalloc (host heap only, for the page table).
  * Fixed-width physical types only (BYTE_ARRAY: PQD_ERR_INVALID_ARG).  d_values: num_slots * elem_size bytes

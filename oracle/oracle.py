@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-OK, EOF, UNEXPECTED_EOF, PANIC, UNSUPPORTED, NOMEM, UNSUPPORTED_TYPE = 0, -1, -2, -3, -4, -5, -6
+OK, EOF, UNEXPECTED_EOF, PANIC, UNSUPPORTED, NOMEM, UNSUPPORTED_TYPE, FLBA_LENGTH = 0, -1, -2, -3, -4, -5, -6, -7
 
 BOOLEAN, INT32, INT64, INT96, FLOAT, DOUBLE, BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY = range(8)
 ENC_PLAIN, ENC_PLAIN_DICTIONARY, ENC_RLE, ENC_BIT_PACKED = 0, 2, 3, 4

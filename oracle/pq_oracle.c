@@ -609,7 +609,14 @@ static int read_data_page(const uint8_t *body, int64_t body_len, const orc_page_
           if (t->values.kind == 0) rc = col_push_fixed(&t->values, dict->fixed.b + k * esz);
           else rc = col_push_str(&t->values, dict->bytes.b + dict->off.v[k], dict->off.v[k + 1] - dict->off.v[k]);
         } else {
-          if (t->values.kind == 0) {
+          if (t->values.kind == 0 && vals.kind == 1 && col->physical_type == ORC_FIXED_LEN_BYTE_ARRAY) {
+            /* DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages of a FIXED_LEN_BYTE_ARRAY column (:684-706): the
+             * reference hands the decoded strings on as they are.  The typed image of the column has type_length
+             * bytes per value, so a string of any other length has no place in it. */
+            int64_t ln = vals.off.v[j + 1] - vals.off.v[j];
+            if (ln != esz) { rc = ORC_FLBA_LENGTH; goto done; }
+            rc = col_push_fixed(&t->values, vals.bytes.b + vals.off.v[j]);
+          } else if (t->values.kind == 0) {
             if (vals.kind != 0 || vals.elem_size != esz) { rc = ORC_UNSUPPORTED; goto done; }
             rc = col_push_fixed(&t->values, vals.fixed.b + j * esz);
           } else {

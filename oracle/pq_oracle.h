@@ -31,7 +31,9 @@ enum {
   ORC_PANIC = -3,          /* slice/index out of range, division by zero, negative make(), endless loop */
   ORC_UNSUPPORTED = -4,    /* fmt.Errorf("Unsupported ...") / "Unknown ..." returns */
   ORC_NOMEM = -5,
-  ORC_UNSUPPORTED_TYPE = -6 /* a value encoding without a typed result for the column's type (stand-in of the checker) */
+  ORC_UNSUPPORTED_TYPE = -6, /* a value encoding without a typed result for the column's type (stand-in of the checker) */
+  ORC_FLBA_LENGTH = -7      /* a delta-encoded string of a FIXED_LEN_BYTE_ARRAY column whose length is not type_length: the
+                               reference hands it on (layout/page.go:689-693, :701-705); the fixed-width image cannot hold it */
 };
 
 /* parquet enums (parquet/parquet.go:28-37, :345-355, :533-538) */

@@ -719,6 +719,41 @@ hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// FIXED_LEN_BYTE_ARRAY columns whose pages are DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY (layout/page.go:684-706: the
+// reference hands the decoded strings on whatever the column's type).  The column's image holds type_length bytes
+// per value, so value i lies at i * type_length: the offsets are known without a scan, and the byte copies of the
+// BYTE_ARRAY path write the image directly.  A string of any other length has no place in it: the page is refused.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flba_delta_check(ChunkCtx c, const uint64_t *__restrict__ pairs, const int64_t *__restrict__ prefix) {
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  const int enc = c.pages[p].encoding;
+  if (enc != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && enc != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  int odd = 0;
+  for (int i = threadIdx.x; i < ps->cnt; i += 256) {
+    int64_t ln = (int64_t)(pairs[base + i] >> 40);
+    if (enc == PQD_ENC_DELTA_BYTE_ARRAY && i > 0) ln += prefix[base + i];   // (the first prefix length is ignored, encodingread.go:427)
+    if (ln != c.type_length) odd = 1;
+  }
+  if (odd) set_status_b(&ps->status, PQD_ERR_REFUSED);
+}
+
+__global__ __launch_bounds__(256) void k_flba_offsets(int64_t n, int64_t type_length, int64_t *__restrict__ doff) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i <= n) doff[i] = i * type_length;
+}
+
+hipError_t launch_flba_delta_offsets(const ChunkCtx &c, const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *doff,
+                                     hipStream_t stream) {
+  if (c.nd > 0) hipLaunchKernelGGL(k_flba_delta_check, dim3(c.nd), dim3(256), 0, stream, c, pairs, prefix);
+  hipLaunchKernelGGL(k_flba_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, n, (int64_t)c.type_length, doff);
+  return hipGetLastError();
+}
+
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
                               hipStream_t stream) {
   const int n_tiles = (int)((n + kScanTile - 1) / kScanTile);

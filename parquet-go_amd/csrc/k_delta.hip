@@ -474,7 +474,9 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   if (pi.encoding != PQD_ENC_DELTA_BINARY_PACKED && n_values != (uint64_t)cnt) return -1;
   const uint32_t n_blocks = (uint32_t)((n_values - 1 + 127) / 128);
   DeltaBlock *tb = table + delta_table_base(pi);
-  const uint8_t *in_last = c.in + ((c.in_len + 3) & ~(int64_t)3) - 4;             // last dword that may be read
+  // last dword that may be read: the one holding the stream's last byte (a call may span several chunk buffers; what
+  // lies between them is not the caller's to give)
+  const uint8_t *in_last = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(src + end - 1u) & ~(uintptr_t)3);
 
   // One round of the chain takes kSub x 64 blocks: every lane asks for the bytes of kSub guessed headers at once (the
   // round trip to memory is what a round costs), then the sub-steps are confirmed in order; the first block of
@@ -493,7 +495,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
       pj_s[s] = (uint64_t)pos + (uint64_t)(64u * (uint32_t)s + (uint32_t)lane) * guess;
       mine_s[s] = s < n_sub && blk < n_blocks && ((s == 0 && lane == 0) || guess != 0) && pj_s[s] + 5 <= end;
       if (mine_s[s]) {
-        // 16 bytes at pj (aligned dwords, clamped at the end of the buffer: bytes past the stream are never looked at)
+        // 20 bytes at pj (aligned dwords, clamped at the end of the stream: bytes past it are never looked at)
         const uint8_t *a0 = src + (uint32_t)pj_s[s];
         const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);

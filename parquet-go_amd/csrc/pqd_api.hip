@@ -342,7 +342,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   if (col->max_def < 0 || col->max_rep < 0) return fail_arg("negative max level");
   if (reinterpret_cast<uintptr_t>(base) & 15u) return fail_arg("device chunk buffer must be 16-byte aligned");
   const bool is_bytes = col->physical_type == PQD_BYTE_ARRAY;
-  if (is_bytes && span > ((size_t)1 << 40)) return fail_arg("BYTE_ARRAY chunks of one call must lie within 1 TiB of device address space");
+  const bool is_flba = col->physical_type == PQD_FIXED_LEN_BYTE_ARRAY;
+  if ((is_bytes || is_flba) && span > ((size_t)1 << 40)) return fail_arg("byte-array chunks of one call must lie within 1 TiB of device address space");
   if (is_bytes && h->no_alloc) return fail_arg("BYTE_ARRAY columns need the allocating entry points");
 
   // ---- host-side page table, built in the block it is uploaded from; the dictionary in effect follows the page
@@ -391,8 +392,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
           // Page.Decode(nil) leaves the indices in place of the values (layout/page.go:139-143): no typed result
           if (cur_dict < 0 && !levels_only) host_fail(PQD_ERR_NO_DICTIONARY, p);
         } else if (e == PQD_ENC_PLAIN) any_plain = true;
-        else if (is_bytes && e == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) any_dlba = true;
-        else if (is_bytes && e == PQD_ENC_DELTA_BYTE_ARRAY) any_dba = true;
+        else if ((is_bytes || is_flba) && e == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) any_dlba = true;   // layout/page.go:684-694
+        else if ((is_bytes || is_flba) && e == PQD_ENC_DELTA_BYTE_ARRAY) any_dba = true;           // layout/page.go:696-706
         else if (!is_bytes && e == PQD_ENC_DELTA_BINARY_PACKED && (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64)) any_delta = true;
         else if (!is_bytes && e == PQD_ENC_BYTE_STREAM_SPLIT && is_real) any_bss = true;   // layout/page.go:707-714
         else if (!is_bytes && e == PQD_ENC_RLE && rle_typed) any_rle = true;               // layout/page.go:657-667
@@ -518,9 +519,15 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   if (levels_only) {
     // nothing but the level arrays
   } else if (!is_bytes) {
-    if ((rc = h->values.ensure(val_bytes))) return rc;
+    if ((slots > 0 || !h->values.fixed) && (rc = h->values.ensure(val_bytes))) return rc;   // (a chunk without slots writes no values: a caller may pass none)
     if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
     if (nullable && slots > 0 && (rc = h->scratch.ensure(12 * (size_t)((slots + 4095) / 4096) + 64))) return rc;
+    if (any_dlba || any_dba) {   // FIXED_LEN_BYTE_ARRAY pages under the delta byte-array encodings: the work arrays of the BYTE_ARRAY path
+      const size_t n8 = 8 * ((size_t)slots + 2) + 64;
+      if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->lens64.ensure(n8))) return rc;
+      if (any_dba && ((rc = h->dba_flags.ensure(4 * (size_t)nd + 64)) || (rc = h->prefix64.ensure(n8)) ||
+                      (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
+    }
   } else {
     const size_t n8 = 8 * ((size_t)slots + 2) + 64;
     if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->offsets.ensure(n8))) return rc;
@@ -787,6 +794,31 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       }
       Prof pf(h, "k_delta_decode");
       HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, h->stream));
+    }
+    if (any_dlba || any_dba) {
+      // FIXED_LEN_BYTE_ARRAY under DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: the kernels of the BYTE_ARRAY path, their
+      // offsets fixed at type_length bytes per value, copy straight into the column's image
+      uint64_t *pairs = static_cast<uint64_t *>(h->pairs.p);
+      int64_t *lens64 = static_cast<int64_t *>(h->lens64.p);
+      int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
+      int64_t *doff = static_cast<int64_t *>(h->doff.p);
+      HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));
+      if (any_dlba) {
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
+        { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
+      }
+      if (any_dba) {
+        HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
+        { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, h->stream)); }
+        { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
+        { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
+      }
+      { Prof pf(h, "k_flba_delta_check"); HIP_TRY(launch_flba_delta_offsets(c, pairs, any_dba ? prefix64 : nullptr, slots, doff, h->stream)); }
+      const int64_t cap = slots * (int64_t)esz;
+      if (any_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, dense_out, doff + slots, cap, h->stream)); }
+      if (any_dba) { Prof pf(h, "k_dba_resolve");
+        HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), dense_out, 1, doff + slots, cap, h->stream)); }
     }
     if (nullable && slots > 0) {
       Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
@@ -1099,8 +1131,14 @@ int pqd_decode_chunk_device_noalloc(int device, void *stream, const void *d_chun
   h->def.p = d_def_levels; h->def.cap = d_def_levels ? 4 * level_slots + 64 : 0;
   h->rep.p = d_rep_levels; h->rep.cap = d_rep_levels ? 4 * level_slots + 64 : 0;
   const void *chunks[1] = {d_chunk};
-  if ((rc = decode_device(h, 1, chunks, &len, pages, &n_pages, col, false))) return rc;
-  if ((rc = finish_call(h))) { set_busy(h, false); return rc; }
+  if ((rc = decode_device(h, 1, chunks, &len, pages, &n_pages, col, false))) {
+    // a launch sequence that failed part way may have left kernels on the stream: they use the shared array, which the
+    // next caller carves anew as soon as the lock is free
+    (void)hipStreamSynchronize(h->stream);
+    set_busy(h, false);
+    return rc;
+  }
+  if ((rc = finish_call(h))) { (void)hipStreamSynchronize(h->stream); set_busy(h, false); return rc; }
   *res = h->result;
   return h->result.status;
   )

@@ -76,6 +76,10 @@ hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *len
 hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream);
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
                               hipStream_t stream);
+// FIXED_LEN_BYTE_ARRAY columns under the two delta byte-array encodings: doff[i] = i * type_length for i in [0, n], and
+// pages holding a string of another length are refused
+hipError_t launch_flba_delta_offsets(const ChunkCtx &c, const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *doff,
+                                     hipStream_t stream);
 // The copies write nothing when the byte total (*total, on the device) exceeds cap, the capacity of bytes_out.
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
                               const int64_t *total, int64_t cap, hipStream_t stream);

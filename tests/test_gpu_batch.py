@@ -272,3 +272,38 @@ def test_delta_byte_array_pages_without_a_restart_are_cut_anyway(dec, oracle, pa
     assert g.status == o.status == 0
     assert np.array_equal(g.offsets, o.offsets)
     assert np.array_equal(g.bytes, o.bytes)
+
+
+def test_delta_pages_ending_chunks_that_end_their_allocations(dec, oracle):
+    # The walk of the block headers asks for 20 bytes at every guessed header.  A call over several device chunks spans
+    # from the lowest to the highest address; reads must stay within each chunk's length rounded up to 16 all the same.
+    # Every chunk here ends exactly where its own device allocation ends, with a block header in its last bytes.
+    import ctypes as C
+    import torch
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(516)
+    parts, ptrs, allocs = [], [], []
+    size = 2 << 20
+    for k in range(5):
+        cb = pg.ChunkBuilder(lead=int(rng.integers(0, 16)))
+        for n in (130 + 128 * k, 1000 + k, 4000):
+            # (the last block holds few values: its header sits within 5 to 19 bytes of the page's end)
+            vals = np.cumsum(rng.integers(0, 3, n)).astype(np.int64)
+            cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, n, pg.delta_encode(vals, np.int64, trim=True))
+        chunk, pages = cb.finish()
+        parts.append((chunk, pages))
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(size)) == 0
+        allocs.append(p)
+        at = p.value + size - (len(chunk) + 15) // 16 * 16
+        assert hip.hipMemcpy(C.c_void_p(at), chunk, C.c_size_t(len(chunk)), C.c_int(1)) == 0
+        ptrs.append(at)
+    try:
+        o = concat_oracle(oracle, parts, pg.INT64)
+        dec.submit_chunks_device(ptrs, [len(c) for c, _ in parts], [p for _, p in parts], pg.INT64)
+        g = dec.fetch()
+        same_table(g, o)
+    finally:
+        for p in allocs:
+            hip.hipFree(p)

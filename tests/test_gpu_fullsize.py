@@ -152,8 +152,62 @@ def test_list_chunk_counts_and_scatter(pq, oracle):
     dense = np.concatenate([chunk[int(e) - 8 * int(k):int(e)] for e, k in zip(ends, nn)]).view("<i8")
     assert dense.size == int(present.sum().item())
     assert torch.equal(vals[present], torch.from_numpy(dense.copy()).cuda())
+    # sampled pages against the oracle: levels, values, nulls, rows (layout/page.go:835-931)
+    rng = np.random.default_rng(55)
+    slot0 = np.concatenate([[0], np.cumsum(pc[:, 2])])
+    for k in sorted(rng.choice(pages.size, 3, replace=False)):
+        o = oracle.read_chunk(chunk, pages[k:k + 1], oracle.INT64, 0, 3, 1)
+        assert o.status == 0 and (o.n_slots, o.n_nulls, o.n_rows) == (int(pc[k, 2]), int(pc[k, 0]), int(pc[k, 1]))
+        lo, hi = int(slot0[k]), int(slot0[k + 1])
+        assert np.array_equal(rl[lo:hi].cpu().numpy(), o.rep_levels) and np.array_equal(dl[lo:hi].cpu().numpy(), o.def_levels)
+        assert np.array_equal(vals[lo:hi].cpu().numpy(), o.values.view("<i8").ravel())
     # row starts: one entry per row and the end marker
     rs = dec.row_starts(r)
     assert rs.size == r.num_rows + 1 and rs[0] == 0 and rs[-1] == n
     assert torch.equal(torch.from_numpy(rs[:-1]).cuda(), torch.nonzero(rl == 0).ravel())
+    dec.close()
+
+
+def test_list_column_as_1024_row_groups(pq, oracle):
+    """The nested-list configuration at its stated shape: 1024 row-group chunks of 1 Mi level slots each (8 pages of
+    128 Ki slots), decoded 64 chunks per call through pqd_decode_chunks_device - the calls the bench times.  Every call
+    is checked through its totals and levels; sampled row groups are compared with the oracle slot for slot: repetition
+    and definition levels, values, nulls and rows (layout/page.go:835-931)."""
+    import torch
+    n_rg, per_call, rg_slots = 1024, 64, 1 << 20
+    rng = np.random.default_rng(1024)
+    sampled = set(int(x) for x in rng.choice(n_rg, 10, replace=False)) | {0, n_rg - 1}
+    dec = pq.Decoder(0)
+    checked = 0
+    for c0 in range(0, n_rg, per_call):
+        parts = [pqgen.list_chunk(0x5EED2000 + k, rg_slots, 128 << 10) for k in range(c0, c0 + per_call)]
+        devs = [to_device(c) for c, _ in parts]
+        torch.cuda.synchronize()
+        dec.submit_chunks_device([t.data_ptr() for t in devs], [c.size for c, _ in parts], [p for _, p in parts], pq.INT64, 0, 3, 1)
+        r = dec.wait(check=True)
+        n = per_call * rg_slots
+        assert r.num_slots == n
+        d = dec.device_result()
+        vals, dl, rl = dev_tensor(d.values, n, "<i8"), dev_tensor(d.def_levels, n, "<i4"), dev_tensor(d.rep_levels, n, "<i4")
+        present = dl == 3
+        assert int((rl == 0).sum().item()) == r.num_rows and int((~present).sum().item()) == r.num_nulls
+        assert int((vals[~present] != 0).sum().item()) == 0
+        # every row group starts a row: its first repetition level is 0
+        assert int(rl[::rg_slots].abs().sum().item()) == 0
+        for k in range(c0, c0 + per_call):
+            if k not in sampled:
+                continue
+            chunk, pages = parts[k - c0]
+            o = oracle.read_chunk(chunk, pages, oracle.INT64, 0, 3, 1)
+            assert o.status == 0 and o.n_slots == rg_slots
+            lo = (k - c0) * rg_slots
+            assert np.array_equal(rl[lo:lo + rg_slots].cpu().numpy(), o.rep_levels), k
+            assert np.array_equal(dl[lo:lo + rg_slots].cpu().numpy(), o.def_levels), k
+            assert np.array_equal(vals[lo:lo + rg_slots].cpu().numpy(), o.values.view("<i8").ravel()), k
+            assert int((rl[lo:lo + rg_slots] == 0).sum().item()) == o.n_rows
+            assert int((dl[lo:lo + rg_slots] != 3).sum().item()) == o.n_nulls
+            checked += 1
+        torch.cuda.synchronize()
+        del devs
+    assert checked == len(sampled)
     dec.close()

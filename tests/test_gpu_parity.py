@@ -1187,3 +1187,77 @@ def test_byte_array_errors(dec, oracle):
     chunk, pages = cb.finish()
     g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
     assert o.status == oracle.PANIC
+
+
+def _fixed_keys(rng, n, tl):
+    """n strings of tl bytes each, sorted, sharing prefixes with their predecessors."""
+    ab = np.frombuffer(b"abc", np.uint8)
+    return sorted(ab[rng.integers(0, 3, tl)].tobytes() for _ in range(n))
+
+
+@pytest.mark.parametrize("tl", [1, 6, 16, 100, 1500])
+def test_flba_under_delta_byte_array_encodings(dec, oracle, tl):
+    # layout/page.go:684-706: a FIXED_LEN_BYTE_ARRAY column whose pages are DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY
+    # (what the reference's writer emits for such a column tagged that way, layout/page.go:179-183), next to PLAIN
+    # and dictionary pages of the same column
+    rng = np.random.default_rng(90 + tl)
+    cb = pg.ChunkBuilder(gap=1, lead=3)
+    sizes = (1, 2, 130, 3000) if tl <= 100 else (1, 2, 70)
+    for n in sizes:
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, n, pg.dlba_encode([rng.integers(0, 256, tl, dtype=np.uint8).tobytes() for _ in range(n)]))
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, n, pg.dba_encode(_fixed_keys(rng, n, tl)))
+    cb.data_page_v1(pg.ENC_PLAIN, 50, rand_dict(rng, pg.FIXED_LEN_BYTE_ARRAY, 50, tl))
+    cb.dict_page(rand_dict(rng, pg.FIXED_LEN_BYTE_ARRAY, 40, tl), 40)
+    cb.data_page_v1(pg.ENC_RLE_DICTIONARY, 777, pg.dict_indices_body(rng.integers(0, 40, 777), 6, rng))
+    cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, 500 if tl <= 100 else 40, pg.dba_encode(_fixed_keys(rng, 500 if tl <= 100 else 40, tl)))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.FIXED_LEN_BYTE_ARRAY, tl)
+    assert o.status == 0 and o.kind == "fixed" and o.values.shape[1] == tl
+
+
+@pytest.mark.parametrize("version", [1, 2])
+@pytest.mark.parametrize("enc", ["dlba", "dba"])
+def test_flba_delta_with_nulls(dec, oracle, enc, version):
+    rng = np.random.default_rng(97)
+    tl = 12
+    cb = pg.ChunkBuilder(lead=1)
+    for n in (10, 4096, 9001):
+        dl, rl = _levels(rng, n, 2, 1)
+        nn = int((dl == 2).sum())
+        if enc == "dlba":
+            body, e = pg.dlba_encode([rng.integers(0, 256, tl, dtype=np.uint8).tobytes() for _ in range(nn)]), pg.ENC_DELTA_LENGTH_BYTE_ARRAY
+        else:
+            body, e = pg.dba_encode(_fixed_keys(rng, nn, tl)), pg.ENC_DELTA_BYTE_ARRAY
+        if nn == 0:
+            body = b""
+        if version == 1:
+            cb.data_page_v1(e, n, body, pg.level_block_v1(rl, 1, rng), pg.level_block_v1(dl, 2, rng))
+        else:
+            cb.data_page_v2(e, n, body, pg.hybrid_encode(rl, 1, rng), pg.hybrid_encode(dl, 2, rng))
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.FIXED_LEN_BYTE_ARRAY, tl, 2, 1)
+    assert o.status == 0 and o.n_nulls > 0
+
+
+@pytest.mark.parametrize("enc", ["dlba", "dba"])
+def test_flba_delta_string_of_another_length_is_refused(dec, oracle, enc):
+    # The reference hands a delta-decoded string on whatever its length (layout/page.go:689-693, :701-705); the
+    # column's fixed-width image cannot hold it: the page is refused, and the pages before it decode.
+    rng = np.random.default_rng(98)
+    tl = 8
+    good = _fixed_keys(rng, 300, tl)
+    odd = list(good)
+    odd[137] = odd[137] + b"x"
+    encode, e = (pg.dlba_encode, pg.ENC_DELTA_LENGTH_BYTE_ARRAY) if enc == "dlba" else (pg.dba_encode, pg.ENC_DELTA_BYTE_ARRAY)
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(e, 300, encode(good))
+    cb.data_page_v1(e, 300, encode(odd))
+    cb.data_page_v1(e, 300, encode(good))
+    chunk, pages = cb.finish()
+    g = dec.decode(chunk, pages, pg.FIXED_LEN_BYTE_ARRAY, tl)
+    o = oracle.read_chunk(chunk, pages, pg.FIXED_LEN_BYTE_ARRAY, tl)
+    assert o.status == oracle.FLBA_LENGTH and o.bad_page == 1
+    assert g.status == -13 and g.bad_page == 1
+    # a column of another physical type still refuses these encodings
+    g = dec.decode(chunk, pages, pg.INT64)
+    assert g.status == -4 and g.bad_page == 0

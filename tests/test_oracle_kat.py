@@ -210,3 +210,25 @@ def test_hybrid_quirks(oracle):
     # 4-byte length prefix when length == 0 (:233-239)
     vals, rc, used = oracle.read_rle_bit_packed_hybrid(struct.pack("<i", 2) + bytes([6, 1, 99]), 1, 0)
     assert rc == 0 and vals.tolist() == [1, 1, 1] and used == 6
+
+
+def test_flba_column_under_delta_byte_array_encodings(oracle):
+    """layout/page.go:684-706 hands delta-decoded strings on for a FIXED_LEN_BYTE_ARRAY column too.  The reference's
+    own byte vectors (encodingwrite_test.go:256-286: "Hello", "World", "Foobar", "ABCDEF") as pages of such a column:
+    with type_length 5 the first two strings fill the fixed-width image, and "Foobar" has no place in it."""
+    import pagegen as pg
+    for name, enc in (("delta_length_byte_array", pg.ENC_DELTA_LENGTH_BYTE_ARRAY), ("delta_byte_array", pg.ENC_DELTA_BYTE_ARRAY)):
+        body = bytes(KAT[name]["cases"][0]["bytes"])
+        cb = pg.ChunkBuilder()
+        cb.data_page_v1(enc, 2, body)     # values[:cnt] with cnt = 2
+        chunk, pages = cb.finish()
+        t = oracle.read_chunk(chunk, pages, oracle.FIXED_LEN_BYTE_ARRAY, 5)
+        assert t.status == 0 and t.kind == "fixed"
+        assert [bytes(r) for r in t.values] == [b"Hello", b"World"]
+        cb = pg.ChunkBuilder()
+        cb.data_page_v1(enc, 4, body)
+        chunk, pages = cb.finish()
+        t = oracle.read_chunk(chunk, pages, oracle.FIXED_LEN_BYTE_ARRAY, 5)
+        assert t.status == oracle.FLBA_LENGTH and t.bad_page == 0
+        t = oracle.read_chunk(chunk, pages, oracle.BYTE_ARRAY)
+        assert t.status == 0 and t.bytes.tobytes() == b"HelloWorldFoobarABCDEF"

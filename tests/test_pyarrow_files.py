@@ -38,6 +38,8 @@ def make_table(n, rng, nulls):
         "str_dlba": mask(np.array(["v" * int(x) for x in rng.integers(0, 30, n)], dtype=object)),
         "str_dba": mask(np.array(keys, dtype=object)),
         "flba": pa.array([bytes(rng.integers(0, 256, 6, dtype=np.uint8)) for _ in range(n)], type=pa.binary(6)),
+        # FIXED_LEN_BYTE_ARRAY under DELTA_BYTE_ARRAY (layout/page.go:696-706): keys that share prefixes
+        "flba_dba": pa.array([None if (nulls and rng.random() < 0.1) else b"key%07d" % (i // 3 * 7) for i in range(n)], type=pa.binary(10)),
     }
     lists = []
     for i in range(n):
@@ -59,7 +61,7 @@ def write_file(path, table, version):
         column_encoding={"i64_delta": "DELTA_BINARY_PACKED", "i32_delta": "DELTA_BINARY_PACKED", "f32_plain": "PLAIN",
                          "f32_bss": "BYTE_STREAM_SPLIT", "f64_bss": "BYTE_STREAM_SPLIT",
                          "bool_plain": "PLAIN", "str_plain": "PLAIN", "str_dlba": "DELTA_LENGTH_BYTE_ARRAY",
-                         "str_dba": "DELTA_BYTE_ARRAY", "flba": "PLAIN"},
+                         "str_dba": "DELTA_BYTE_ARRAY", "flba": "PLAIN", "flba_dba": "DELTA_BYTE_ARRAY"},
         row_group_size=len(table) // 2 + 1)
 
 

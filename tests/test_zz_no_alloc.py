@@ -76,6 +76,51 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
         chunk, pages = pqgen.dict_chunk(0x7C, 70000, 16, 40000, 8192)
         run_both(torch, pq, dec, chunk, pages, pg.INT32)
 
+        # value buffers whose sizes are no multiple of 16 bytes (a 16-byte store that spilled past the last value would
+        # land in the canary): INT32 dictionary, PLAIN, a nullable PLAIN column, BOOLEAN
+        for n in (4097, 1001, 13):
+            cb = pg.ChunkBuilder(lead=3)
+            cb.dict_page(rng.integers(0, 1000, 50).astype(np.int32).tobytes(), 50)
+            cb.data_page_v1(pg.ENC_RLE_DICTIONARY, n, pg.dict_indices_body(rng.integers(0, 50, n), 6, rng))
+            chunk, pages = cb.finish()
+            run_both(torch, pq, dec, chunk, pages, pg.INT32)
+            cb = pg.ChunkBuilder()
+            cb.data_page_v1(pg.ENC_PLAIN, n, rng.integers(-9, 9, n).astype(np.int32).tobytes())
+            chunk, pages = cb.finish()
+            run_both(torch, pq, dec, chunk, pages, pg.INT32)
+            dl = rng.integers(0, 2, n)
+            cb = pg.ChunkBuilder()
+            cb.data_page_v1(pg.ENC_PLAIN, n, rng.integers(-9, 9, int(dl.sum())).astype(np.int32).tobytes(), b"", pg.level_block_v1(dl, 1, rng))
+            chunk, pages = cb.finish()
+            run_both(torch, pq, dec, chunk, pages, pg.INT32, 0, 1, 0)
+            cb = pg.ChunkBuilder()
+            cb.data_page_v1(pg.ENC_PLAIN, n, np.packbits(rng.integers(0, 2, n).astype(np.uint8), bitorder="little").tobytes())
+            chunk, pages = cb.finish()
+            run_both(torch, pq, dec, chunk, pages, pg.BOOLEAN)
+        # a chunk without level slots needs no value buffer
+        cb = pg.ChunkBuilder()
+        cb.dict_page(rng.integers(0, 1000, 50).astype(np.int32).tobytes(), 50)
+        chunk, pages = cb.finish()
+        a = np.frombuffer(chunk, np.uint8)
+        d_in = torch.zeros(a.size + 64, dtype=torch.uint8, device="cuda")
+        d_in[:a.size].copy_(torch.from_numpy(a.copy()))
+        torch.cuda.synchronize()
+        rc, r = pq.binding.decode_chunk_device_noalloc(0, 0, d_in.data_ptr(), a.size, pages, pg.INT32, 0, 0, 0, 0, 0, 0, 0, 0)
+        assert rc == 0 and r.num_slots == 0, (rc, pq.lib().pqd_last_error())
+
+        # the property the entry point is named for: a warmed-up call leaves the device's free memory as it was
+        chunk, pages = pqgen.dict_chunk(0x77, 300000, 12, 4096, 65536)
+        a = np.frombuffer(chunk, np.uint8)
+        d_in = torch.zeros(a.size + 64, dtype=torch.uint8, device="cuda")
+        d_in[:a.size].copy_(torch.from_numpy(a.copy()))
+        vals = dev_bytes(torch, 300000 * 4)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for _ in range(3):
+            rc, r = pq.binding.decode_chunk_device_noalloc(0, 0, d_in.data_ptr(), a.size, pages, pg.INT32, 0, 0, 0, vals.data_ptr(), 300000 * 4, 0, 0, 0)
+            assert rc == 0
+        assert torch.cuda.mem_get_info()[0] == free_before, "device memory was allocated or freed during the calls"
+
         # refusals: more work space than the array holds, an output that is too small, BYTE_ARRAY
         chunk, pages = pqgen.list_chunk(0x7D, 6 << 20, 1 << 20)
         a = np.frombuffer(chunk, np.uint8)
