@@ -137,7 +137,8 @@ enum {
   PQD_OPT_PLAIN_SCATTER = 3,  /* 0 / 1: nullable PLAIN columns scattered straight from the pages */
   PQD_OPT_SPLIT = 4,          /* 0 / 1: head of a mid-size dictionary kept in LDS */
   PQD_OPT_POISON = 5,         /* 1: every work and output buffer is filled with 0xFF before each call (debugging aid) */
-  PQD_OPT_DELTA_BLOCKS = 6,   /* 0 / 1: DELTA_BINARY_PACKED streams decoded block-parallel from a table of block starts */
+  PQD_OPT_DELTA_BLOCKS = 6,   /* 0 / 1 / 2: DELTA_BINARY_PACKED streams decoded block-parallel (0: a wavefront per page); 2: the block headers of
+                                 every stream are walked first, 1: streams whose blocks all look one length long skip that walk */
   PQD_OPT_FUSED = 7,          /* 0 / 1: index streams of large pages walked and expanded by one workgroup per page, in one pass */
   PQD_OPT_COUNT = 8
 };

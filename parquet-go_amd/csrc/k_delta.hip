@@ -423,6 +423,7 @@ struct DeltaWork {
   int64_t n_units;
   int32_t ushift;       // a unit is 2^ushift blocks (3 .. 6), chosen per call from the bytes the pages spend per value
   int32_t win_bytes;    // LDS window over the packed bytes of a unit (the launch's dynamic LDS)
+  int32_t spec;         // pages whose blocks all have one length skip the walk (0: every page is walked)
 };
 
 // A unit is 2^ushift blocks, as many as fit the LDS window (at most 64: one block per lane).  What a unit costs beyond
@@ -439,9 +440,62 @@ constexpr int kMinWinBytes = 2560;      // two blocks of the widest kind and the
 __device__ __forceinline__ int64_t delta_table_base(const PageIn &pi) { return (pi.slot_base >> 7) + 3 * (int64_t)pi.data_idx; }
 __device__ __forceinline__ int64_t delta_unit_base(const PageIn &pi, int ushift) { return (pi.slot_base >> (7 + ushift)) + (int64_t)pi.data_idx; }
 
+// One block header out of the 16 bytes that start at it (x[0..3], little endian): the minimum delta (a varint of at most ten
+// bytes), the four miniblock widths, and from them where the block's data starts and how long the block is.  pj: position
+// of the header in the stream, end: length of the stream, blk: index of the block.  good: the header and the miniblocks the
+// stream still needs at this block (encodingread.go:372: reading stops with the count) lie inside the stream and no width
+// exceeds 64.
+struct DeltaHdr {
+  bool good;
+  uint32_t size, data_off, widths, dbytes;
+  uint64_t md;
+};
+__device__ __forceinline__ DeltaHdr delta_parse_header(const uint32_t x[4], uint32_t pj, uint32_t end, uint32_t blk, uint64_t n_values) {
+  DeltaHdr h{false, 0u, 0u, 0u, 0u, 0ull};
+  uint32_t hl = 0, shift = 0;
+  bool closed = false;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    if (!closed) {
+      const uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      hl++;
+      if (shift < 64) h.md |= (uint64_t)(b & 0x7Fu) << shift;
+      shift += 7;
+      closed = (b & 0x80u) == 0;
+    }
+  }
+  if (closed && (uint64_t)pj + hl + 4 <= end) {
+    const uint64_t x64lo = ((uint64_t)x[1] << 32) | x[0], x64hi = ((uint64_t)x[3] << 32) | x[2];
+    const uint32_t wb = hl < 8 ? (uint32_t)((x64lo >> (8u * hl)) | (hl ? x64hi << (64u - 8u * hl) : 0ull)) : (uint32_t)(x64hi >> (8u * (hl - 8u)));
+    const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
+    const int need = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
+    uint32_t bytes = 0, wmax = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
+      if (m < need) { bytes += 4u * wm; h.widths |= wm << (8 * m); wmax = wm > wmax ? wm : wmax; }
+    }
+    h.data_off = pj + hl + 4u;
+    h.dbytes = bytes;
+    h.size = hl + 4u + bytes;
+    h.good = wmax <= 64u && (uint64_t)h.data_off + bytes <= end;
+  }
+  return h;
+}
+
+// What a page whose blocks all have one length needs instead of a walk (k_delta_units then reads the headers itself).
+struct DeltaSpec {
+  uint32_t L;         // the length of every block but the last; 0: the page was walked
+  uint32_t q0;        // position of the first block header
+  uint32_t end_pos;   // where the last block ends
+  uint32_t slen;      // length of the stream
+  uint64_t n_values;
+};
+
 // -> the number of blocks, or -1 when the page is left to k_delta_decode
 __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int ushift, int lane,
-                                              int64_t *src_off_out, uint64_t *first_out) {
+                                              int64_t *src_off_out, uint64_t *first_out, int spec_win, DeltaSpec *spec) {
+  spec->L = 0;
   if (lane == 0) ps->delta_fast = 0;
   const int64_t cnt = ps->cnt;
   if (ps->status != 0 || cnt <= 0) return -1;
@@ -478,6 +532,61 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   // lies between them is not the caller's to give)
   const uint8_t *in_last = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(src + end - 1u) & ~(uintptr_t)3);
 
+  auto header_at = [&](uint64_t pj, uint32_t x[4]) {     // the 16 bytes at stream position pj (pj + 5 <= end)
+    const uint8_t *a0 = src + (uint32_t)pj;
+    const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
+    const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);
+    const uint32_t *wl = reinterpret_cast<const uint32_t *>(in_last);
+    uint32_t dw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) dw[i] = *(w0 + i <= wl ? w0 + i : wl);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], al * 8u);
+  };
+
+  // Streams of steady width - timestamps, counters - consist of blocks of one length L.  Then block k starts at q + k L and
+  // nothing has to be walked: the units read their own headers out of the bytes they stage anyway, check that every block
+  // is L long and hand the verdict down the page with their totals (k_delta_units); a page where that fails is decoded
+  // again by k_delta_decode.  Tried here on 64 blocks spread over the page (the last one among them, whose length may
+  // differ); anything else is walked as before.
+  if (spec_win > 0 && n_blocks >= 2u && (uint64_t)q + 5 <= end) {
+    uint32_t x[4];
+    header_at(q, x);
+    const DeltaHdr h0 = delta_parse_header(x, q, end, 0u, n_values);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.size);
+    const bool fits = h0.good && L != 0u && ((uint64_t)L << ushift) + 96u <= (uint64_t)spec_win;
+    if (__builtin_amdgcn_readfirstlane((int)fits)) {
+      const uint32_t k = (uint32_t)(((uint64_t)(n_blocks - 1u) * (uint32_t)lane) / 63u);
+      const uint64_t pj = (uint64_t)q + (uint64_t)k * L;
+      bool ok = pj + 5 <= end;
+      DeltaHdr hk{false, 0u, 0u, 0u, 0u, 0ull};
+      if (ok) {
+        header_at(pj, x);
+        hk = delta_parse_header(x, (uint32_t)pj, end, k, n_values);
+        ok = hk.good && (hk.size == L || k == n_blocks - 1u);
+      }
+      if (__ballot(ok) == ~0ull) {
+        const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)hk.size, 63);
+        const uint32_t end_pos = q + (n_blocks - 1u) * L + size_last;      // (<= end: the last block is good)
+        // (the last unit holds the last block, which may be longer than the others: it must fit the window too)
+        const uint32_t n_last = n_blocks - (((n_blocks - 1u) >> ushift) << ushift);
+        if ((uint64_t)(n_last - 1u) * L + size_last + 96u > (uint64_t)spec_win) goto walk;
+        if (lane == 0) {
+          tb[n_blocks] = DeltaBlock{0u, 0u, hdr[3]};
+          tb[n_blocks + 1] = DeltaBlock{0u, 0u, (uint64_t)src_off};
+          ps->aux0 = src_off + (int64_t)end_pos;
+          ps->aux1 = (int64_t)n_values;
+          ps->delta_fast = 1;
+        }
+        spec->L = L; spec->q0 = q; spec->end_pos = end_pos; spec->slen = end; spec->n_values = n_values;
+        *src_off_out = src_off;
+        *first_out = hdr[3];
+        return (int64_t)n_blocks;
+      }
+    }
+  }
+
+walk:
   // One round of the chain takes kSub x 64 blocks: every lane asks for the bytes of kSub guessed headers at once (the
   // round trip to memory is what a round costs), then the sub-steps are confirmed in order; the first block of
   // another length ends the round.
@@ -520,37 +629,8 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
         uint32_t x[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[s][i + 1], dw[s][i], al * 8u);
-        // minimum delta: a varint of at most 10 bytes
-        uint32_t hl = 0, shift = 0;
-        bool closed = false;
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-          if (!closed) {
-            const uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            hl++;
-            if (shift < 64) md |= (uint64_t)(b & 0x7Fu) << shift;
-            shift += 7;
-            closed = (b & 0x80u) == 0;
-          }
-        }
-        if (closed && (uint64_t)pj + hl + 4 <= end) {
-          const uint64_t x64lo = ((uint64_t)x[1] << 32) | x[0], x64hi = ((uint64_t)x[3] << 32) | x[2];
-          const uint32_t wb = hl < 8 ? (uint32_t)((x64lo >> (8u * hl)) | (hl ? x64hi << (64u - 8u * hl) : 0ull)) : (uint32_t)(x64hi >> (8u * (hl - 8u)));
-          // miniblocks the stream still needs at this block (encodingread.go:372: reading stops with the count)
-          const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
-          const int need = remaining >= 128 ? 4 : (int)((remaining + 31) / 32);
-          uint32_t bytes = 0, wmax = 0;
-          widths = 0;
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const uint32_t wm = (wb >> (8 * m)) & 0xFFu;
-            if (m < need) { bytes += 4u * wm; widths |= wm << (8 * m); wmax = wm > wmax ? wm : wmax; }
-          }
-          data_off = pj + hl + 4u;
-          dbytes = bytes;
-          size = hl + 4u + bytes;
-          good = wmax <= 64u && (uint64_t)data_off + bytes <= end;
-        }
+        const DeltaHdr h = delta_parse_header(x, pj, end, blk, n_values);
+        size = h.size; data_off = h.data_off; widths = h.widths; dbytes = h.dbytes; md = h.md; good = h.good;
       }
       // lane j sits at a true block start when every lane before it is good and as long as the guess
       const uint64_t okm = __ballot(good && size == guess);
@@ -603,15 +683,26 @@ __global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, i
   const int64_t range = ((pi.slot_base + nvp) >> (7 + w.ushift)) - (pi.slot_base >> (7 + w.ushift)) + 1;
   int64_t src_off = 0;
   uint64_t first_raw = 0;
-  const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, w.ushift, lane, &src_off, &first_raw) : -1;
+  DeltaSpec spec;
+  spec.L = 0;
+  const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, w.ushift, lane, &src_off, &first_raw,
+                                                          w.spec ? w.win_bytes : 0, &spec) : -1;
   // the page's units: the ones its blocks fill get their records, the rest of its range holds nothing
   const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + ((int64_t)1 << w.ushift) - 1) >> w.ushift);     // (a stream of one value still has its first value to write)
   for (int64_t j = lane; j < range; j += 64) {
     if (ub + j >= w.n_units) continue;
     DeltaUnit *r = w.units + ub + j;
     if (j < ng) {
-      r->g = (uint32_t)j; r->n_blocks = (uint32_t)nb; r->spare = 0;
+      r->g = (uint32_t)j; r->n_blocks = (uint32_t)nb; r->spare = spec.L;
       r->tbase = delta_table_base(pi); r->src_off = src_off; r->out_base = c.state[p].dense_base; r->cnt = c.state[p].cnt;
+      if (spec.L != 0u) {
+        // blocks of one length: the unit's bytes follow from its index; in place of the table's base the record carries
+        // the stream's length and value count, which the unit needs to read the headers as the walk would
+        const uint64_t b_lo = (uint64_t)j << w.ushift, b_hi = ((uint64_t)j + 1) << w.ushift;
+        r->win_start = spec.q0 + (uint32_t)b_lo * spec.L;
+        r->win_end = b_hi >= (uint64_t)nb ? spec.end_pos : spec.q0 + (uint32_t)b_hi * spec.L;
+        r->tbase = (int64_t)((uint64_t)spec.slen | (spec.n_values << 32));
+      }
       r->first_raw = first_raw;
       r->page = p;
     } else {
@@ -721,9 +812,9 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   auto r64 = [&](int i) { return (int64_t)(((uint64_t)r32(i + 1) << 32) | r32(i)); };
   const int p = (int)r32(0);
   if (p < 0) return;
-  const uint32_t g = r32(1), n_blocks = r32(2), win_start = r32(3), win_end = r32(4);
+  const uint32_t g = r32(1), n_blocks = r32(2), win_start = r32(3), win_end = r32(4), spec_len = r32(5);
   const int64_t tbase = r64(6), cnt = r64(12);
-  const DeltaBlock *tb = w.blocks + tbase;
+  const DeltaBlock *tb = w.blocks + (spec_len ? 0 : tbase);
   const T first = DeltaTraits<T>::zigzag((uint64_t)r64(14));
   const uint8_t *src = c.in + r64(8);
   const int64_t lim = (int64_t)((c.in + c.in_len) - src);          // bytes of the buffer from src on
@@ -735,7 +826,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
 
   // one block per lane (of the first 32)
   DeltaBlock E{0u, 0u, 0ull};
-  if ((uint32_t)lane < nb_here) E = tb[b0 + (uint32_t)lane];
+  if ((uint32_t)lane < nb_here && spec_len == 0u) E = tb[b0 + (uint32_t)lane];
   // The unit's bytes, when the window holds them all, are asked for at once with the table entries (the record
   // names the range); otherwise the window moves over the blocks.
   uint32_t win_a0 = win_start - ((src_al + win_start) & 15u);
@@ -756,6 +847,37 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
       if (o0 + 1024 * i < (int64_t)end) win4[(uint32_t)(16 * lane + 1024 * i) >> 4] = x[i];
   };
   if (one_window) fill_window(win_a0, win_end);
+  if (spec_len != 0u) {
+    // A page taken to consist of blocks of one length (k_delta_blocks): no table; block j of the unit starts spec_len bytes
+    // after block j - 1, and every lane reads its block's header out of the window.  That holds for this unit when each of
+    // its blocks (the page's last one aside) turns out spec_len long, and for the page when it holds for every unit: a unit
+    // that finds otherwise says so in the word it publishes, the units behind it stop when they read that, and the page is
+    // decoded again by k_delta_decode.
+    const uint32_t slen = (uint32_t)tbase;
+    const uint64_t n_values = (uint64_t)tbase >> 32;
+    bool ok = one_window;
+    __syncthreads();
+    if (ok && (uint32_t)lane < nb_here) {
+      const uint32_t pj = win_start + (uint32_t)lane * spec_len;
+      const uint32_t r = pj - win_a0;
+      const uint32_t *q = win + (r >> 2);
+      const uint32_t sh = (r & 3u) * 8u;
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+      const uint32_t x[4] = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), __builtin_amdgcn_alignbit(d3, d2, sh),
+                             __builtin_amdgcn_alignbit(d4, d3, sh)};
+      const DeltaHdr h = delta_parse_header(x, pj, slen, b0 + (uint32_t)lane, n_values);
+      ok = h.good && (h.size == spec_len || b0 + (uint32_t)lane + 1u == n_blocks);
+      E = DeltaBlock{h.data_off, h.widths, h.md};
+    }
+    if (__ballot(!ok) != 0ull) {
+      if (lane == 0) {
+        __hip_atomic_store(&w.gsum[2 * u], 3ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.gsum[2 * u + 1], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.state[p].delta_fast = 2;
+      }
+      return;
+    }
+  }
   const uint32_t wsum = (E.widths & 0xFFu) + ((E.widths >> 8) & 0xFFu) + ((E.widths >> 16) & 0xFFu) + (E.widths >> 24);
   const uint32_t data_end = E.data_off + 4u * wsum;
   if ((uint32_t)lane < kUnitBlocks) s_ent[lane] = E;
@@ -861,7 +983,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
         if (spins > 1u) __builtin_amdgcn_s_sleep(2);
         poll_raw<sizeof(T) == 8>(slot, &a, &b);
       }
-      late = late || (a >> 32) == 0 || (b >> 32) == 0;
+      late = late || (a >> 32) != 1 || (b >> 32) == 0;     // (never came, or: a unit in front found a block of another length)
       v = (T)((b << 32) | (uint32_t)a);
     }
     before += bcast_lane(wave_incl_scan(v, lane), 63);
@@ -985,7 +1107,7 @@ size_t delta_work_bytes(int64_t slots, int nd) {
 }
 
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               double bytes_per_value, hipStream_t stream) {
+                               double bytes_per_value, bool spec, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   if (work) {
     // Units as large as the window allows, the window as small as the units need: from the bytes the pages spend per
@@ -1007,6 +1129,7 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     w.n_units = (int64_t)(((size_t)slots >> (7 + ushift)) + (size_t)c.nd);
     w.ushift = ushift;
     w.win_bytes = win_bytes;
+    w.spec = spec ? 1 : 0;
     hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
     const dim3 grid((unsigned)w.n_units);
     const size_t shmem = (size_t)win_bytes + kWinSlack;

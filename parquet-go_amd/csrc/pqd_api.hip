@@ -153,7 +153,7 @@ const Defaults &defaults() {
     if (std::getenv("PQD_NO_PLAIN_SCATTER")) x.opt[PQD_OPT_PLAIN_SCATTER] = 0;
     if (const char *e = std::getenv("PQD_SPLIT")) x.opt[PQD_OPT_SPLIT] = e[0] == '1';
     if (const char *e = std::getenv("PQD_POISON")) x.opt[PQD_OPT_POISON] = e[0] == '1';
-    if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] - '0';
     if (const char *e = std::getenv("PQD_FUSED")) x.opt[PQD_OPT_FUSED] = e[0] == '1';
     const char *e = std::getenv("PQD_HEAVY_LANES");
     const int v = e ? std::atoi(e) : 0;
@@ -608,6 +608,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
 
   uint8_t *dense_out = static_cast<uint8_t *>(nullable ? h->dense.p : h->values.p);
   void *dtab = h->opt[PQD_OPT_DELTA_BLOCKS] == 0 ? nullptr : h->delta_blocks.p;
+  const bool dspec = h->opt[PQD_OPT_DELTA_BLOCKS] != 2;     // (2: every stream's block headers are walked)
 
   // LDS reserved per tile for packed bytes.  Levels: the width is known here.  Dictionary indices: the width is
   // inside the page, so size it from the densest page's bytes per value (a tile that needs more still decodes,
@@ -736,13 +737,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
       HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, h->stream)); }
+      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream)); }
       { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
       { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
     }
@@ -793,7 +794,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         if (pi.data_idx >= 0 && pi.encoding == PQD_ENC_DELTA_BINARY_PACKED && pi.num_values > 0) { db += pi.body_len; dv += pi.num_values; }
       }
       Prof pf(h, "k_delta_decode");
-      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, h->stream));
+      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, dspec, h->stream));
     }
     if (any_dlba || any_dba) {
       // FIXED_LEN_BYTE_ARRAY under DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: the kernels of the BYTE_ARRAY path, their
@@ -804,13 +805,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       int64_t *doff = static_cast<int64_t *>(h->doff.p);
       HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));
       if (any_dlba) {
-        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
         { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
       }
       if (any_dba) {
         HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-        { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, h->stream)); }
-        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, h->stream)); }
+        { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream)); }
         { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
         { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
       }

@@ -66,8 +66,9 @@ hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, ui
 // decode every page with the wavefront-per-page kernel
 size_t delta_work_bytes(int64_t slots, int nd);
 // bytes_per_value: what the pages of this encoding spend per value (sets how many blocks a wavefront takes at once); 0: not known
+// spec: pages whose blocks all look one length long skip the walk of their block headers (the units check the guess)
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               double bytes_per_value, hipStream_t stream);
+                               double bytes_per_value, bool spec, hipStream_t stream);
 
 // ---- k_bytes.hip ----
 // dict_pages == nullptr: the PLAIN data pages; else the listed dictionary pages

@@ -2,7 +2,7 @@
 hundred thousand, stretches of blocks of one length (every miniblock forced to the same width, so that the walk of the
 block headers takes its widest rounds), stretches whose lengths change block by block, width 0, deltas that wrap.
 Compared with the oracle.
-python tests/delta_sweep.py <first_seed> <n_seeds>   (needs a GPU; not collected by pytest)"""
+python tests/delta_sweep.py <first_seed> <n_seeds> [delta_blocks 0|1|2]   (needs a GPU; not collected by pytest)"""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
@@ -15,6 +15,8 @@ from test_gpu_parity import check_same
 
 first, n_seeds = int(sys.argv[1]), int(sys.argv[2])
 dec = pq.Decoder(0)
+if len(sys.argv) > 3:       # PQD_OPT_DELTA_BLOCKS: 0 a wavefront per page, 1 block-parallel, 2 block-parallel with every stream walked
+    dec.set_option(pq.binding.OPT_DELTA_BLOCKS, int(sys.argv[3]))
 t0, fails = time.time(), []
 for si in range(n_seeds):
     seed = first + 15485863 * si

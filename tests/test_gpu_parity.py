@@ -520,7 +520,7 @@ def test_delta_binary_packed(dec, oracle, dtype, ptype):
     check_same(dec, oracle, chunk, pages, ptype)
 
 
-@pytest.mark.parametrize("blocks", [1, 0])
+@pytest.mark.parametrize("blocks", [1, 2, 0])
 @pytest.mark.parametrize("n_pages,page_values", [(3, 70001), (600, 1500), (2100, 700)])
 def test_delta_block_parallel_and_wave_per_page_agree_with_the_oracle(dec, oracle, n_pages, page_values, blocks):
     # standard 128 / 4 streams go through a table of block starts and are decoded by one, four or sixteen wavefronts
@@ -560,6 +560,47 @@ def test_delta_page_of_constant_blocks_with_a_few_of_the_widest_kind(dec, oracle
         cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, n, pg.delta_encode_fast(vals, np.int64))
     chunk, pages = cb.finish()
     g, o = check_same(dec, oracle, chunk, pages, pg.INT64)
+    assert o.status == 0
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+@pytest.mark.parametrize("dtype,ptype", [(np.int64, pg.INT64), (np.int32, pg.INT32)])
+def test_delta_blocks_of_one_length_but_for_a_few(dec, oracle, dtype, ptype, blocks):
+    # Pages whose blocks all have one length skip the walk of their block headers: block k is taken to start k lengths
+    # after the first, 64 blocks spread over the page are tried, and the wavefronts that decode the blocks check the rest.
+    # Here every block is 198 bytes long, except (a) none, (b) two neighbours that are 4 bytes longer and 4 bytes shorter
+    # - every block behind them starts where it would anyway, so the 64 trials see nothing -, (c) the same pair inside the
+    # page's first 64 blocks and inside its last ones, (d) one longer block (everything behind it moves), (e) a last
+    # block of wider deltas than the rest.  encodingread.go:329-383.
+    dec.set_option(6, blocks)                # PQD_OPT_DELTA_BLOCKS
+    rng = np.random.default_rng(4100 + ptype)
+    cb = pg.ChunkBuilder(gap=3, lead=2)
+
+    def page(n_blocks, pairs=(), longer=(), wide_tail=False, tail=17):
+        d = rng.integers(1000, 1000 + 4096, n_blocks * 128 + tail).astype(np.int64)
+        for b in range(n_blocks):
+            d[b * 128] = 1000                                   # every block's minimum
+            d[b * 128 + 1:b * 128 + 128:32] = 1000 + 4095       # twelve bits in every miniblock
+        for a in pairs:
+            d[a * 128 + 5] = 1000 + 5000                        # thirteen bits in block a's first miniblock
+            d[(a + 1) * 128:(a + 1) * 128 + 32] = rng.integers(1000, 1000 + 2048, 32)
+            d[(a + 1) * 128] = 1000
+            d[(a + 1) * 128 + 1] = 1000 + 2047                  # eleven in the next block's
+        for a in longer:
+            d[a * 128 + 70] = 1000 + 9000
+        if wide_tail:
+            d[n_blocks * 128:] = rng.integers(1000, 1000 + (1 << 20), tail)
+        vals = (7 + np.concatenate([[0], np.cumsum(d)])).astype(dtype)
+        cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, len(vals), pg.delta_encode_fast(vals, dtype))
+
+    page(200)
+    page(200, pairs=(76,))
+    page(400, pairs=(10, 395))
+    page(300, longer=(150,))
+    page(260, wide_tail=True)
+    page(64, pairs=(30,), tail=1)
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, ptype)
     assert o.status == 0
 
 
