@@ -97,7 +97,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    widths = [int(x) for x in args.widths.split(",")]
+    widths = [int(x) for x in args.widths.split(",") if x.strip().isdigit()]     # ("none": the other encodings only, a development aid)
     n_values, page_values = args.values, args.page_values
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 
@@ -328,6 +328,20 @@ def main():
     if not args.no_extra:
         extra = run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample if orc is not None else None, cpu_entry, to_device)
 
+    # HBM bytes per decode call of the other encodings, from the committed counter summary of these very workloads
+    # (profiles/collect.sh: rocprofv3 cannot run inside this process), next to their algorithmic bytes
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tex = json.load(f).get("extras", {})
+    except (OSError, ValueError):
+        tex = {}
+    for name, e in extra.items():
+        t = tex.get(name)
+        if t and isinstance(e, dict) and e.get("in_bytes") and t.get("in_bytes") == e.get("in_bytes") and t.get("out_bytes") == e.get("out_bytes"):
+            e["traffic"] = t["traffic"]
+            e["traffic_over_algorithmic"] = round(t["traffic"] / (e["in_bytes"] + e["out_bytes"]), 3)
+            e["traffic_source"] = "profiles/traffic.json (builder's rocprofv3 --pmc passes over this workload, not this run): 2*FETCH_SIZE + WRITE_SIZE over all kernels of one decode call"
+
     if rank == 0:
         res = {
             "metric": "device-resident decoded GB/s, INT32 RLE_DICTIONARY (bit widths 1-20)",
@@ -417,6 +431,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
                  "decoded_GBps": round(n * esz / best / 1e9, 1), "ms": round(best * 1e3, 3),
                  "alg_GBps": round((in_bytes + n * esz) / best / 1e9, 1),
                  "roofline_frac": round((in_bytes + n * esz) / best / 1e9 / HBM_PEAK_GBPS, 4),
+                 "in_bytes": in_bytes, "out_bytes": n * esz,
                  "kernel_ms": round(kms, 3),
                  "kernel_roofline_frac": round((in_bytes + n * esz) / kms / 1e6 / HBM_PEAK_GBPS, 4) if kms else None}
             if cpu_sample:
@@ -502,6 +517,7 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
                  "decoded_GBps": round(out_bytes / best / 1e9, 1), "ms": round(best * 1e3, 3),
                  "roofline_frac": round((in_bytes + out_bytes) / best / 1e9 / HBM_PEAK_GBPS, 4),
                  "rows": int(r.num_rows), "nulls": int(r.num_nulls),
+                 "in_bytes": in_bytes, "out_bytes": out_bytes,
                  "kernel_ms": {k_: round(v[0], 3) for k_, v in kt.items()}}
             if cpu_sample:
                 k = min(32, len(pages))

@@ -5,8 +5,12 @@
 // It defines the four read functions reader/columnbuffer.go calls - ReadPage (layout/page.go:721),
 // ReadPageRawData (:395), (*Page).GetRLDLFromRawData (:433), (*Page).GetValueFromRawData (:562) - with their
 // signatures, results and error values unchanged, so reader/columnbuffer.go and reader/columnreader.go compile and
-// run as they are.  The CPU definitions of the same four functions move, verbatim, from layout/page.go into a file
-// that carries `//go:build !pqgpu` (see INTEGRATION.md); nothing else in the repository changes.
+// run as they are.  The reference's own definitions of the four stay in the package under private names (readPageCPU,
+// readPageRawDataCPU, getRLDLFromRawDataCPU, getValueFromRawDataCPU: page_read_cpu.go, compiled under both tags, see
+// INTEGRATION.md) and this file hands every chunk it does not take to them: compressed chunks (the reference's writer
+// compresses with SNAPPY unless told otherwise, writer/writer.go:63-65) and chunks holding a page the library answers
+// with PQD_ERR_UNSUPPORTED_*, PQD_ERR_BIT_WIDTH, PQD_ERR_NO_DICTIONARY or PQD_ERR_REFUSED.  A build with the tag reads
+// every file the reference reads.
 // (*Page).Decode (:139) stays where it is: the pages handed out here already hold the looked-up values and say so
 // in their header (Encoding PLAIN), which makes Decode return at its first test of the encoding.
 //
@@ -16,11 +20,18 @@
 // (numValues, numRows) the reference returns for that page.  The state is keyed by the thrift reader:
 // ColumnBufferType opens a new one for every row group (reader/columnbuffer.go:95-99).
 //
-// Source only: written without a Go toolchain at hand; parquet-go_amd/layout_gpu.py makes the same calls in the same
-// order and is what the tests drive.
+// Source only: written without a Go toolchain at hand and never compiled; parquet-go_amd/layout_gpu.py makes the same
+// calls in the same order (the hand-over to the CPU functions included) and is what the tests drive.
+//
+// Lifetimes: a chunk's handle goes back to a bounded free list when the chunk's last page has been handed out, at
+// io.EOF, or when the chunk goes over to the CPU functions - not in a finalizer.  State is keyed by the address of the
+// thrift reader (and of pages handed out raw), because neither type can carry a field of ours without touching the
+// reference's files; the entries are small Go structs once the handle is back, and finalizers remove them.  A host that
+// wants nothing left behind between collections calls ReleaseReader(thriftReader) when it drops a reader.
 package layout
 
 import (
+	"bytes"
 	"fmt"
 	"io"
 	"os"
@@ -55,35 +66,47 @@ func newDecoded(first, last, lead int, res *pqdecode.Result) *decoded {
 func (d *decoded) covers(k int) bool { return d != nil && d.first <= k && k < d.last }
 
 type pageError struct {
-	page int
-	err  error
+	page   int
+	err    error
+	status int
 }
 
 // chunkPager stands for the thrift reader positioned inside one column chunk.
 type chunkPager struct {
-	h        *pqdecode.Handle
-	chunk    []byte // page-locked input buffer of the handle
+	h        *pqdecode.Handle // nil once the chunk is done with the GPU (handed back deterministically, see release)
+	chunk    []byte           // page-locked input buffer of the handle while h != nil; a Go copy (or nil) afterwards
 	descs    []pqdecode.PageDesc
 	col      pqdecode.Column
 	cursor   int
-	dictIdx  int // dictionary page handed out last, -1: none
+	dictIdx  int   // dictionary page handed out last, -1: none
+	dictPage *Page // that page as the caller holds it (ColumnBufferType.DictPage)
 	full     *decoded
 	levels   *decoded
 	errFull  *pageError
 	errLevel *pageError
+	rawOut   int // pages handed out by ReadPageRawData whose values have not been asked for
+
+	// cpu != nil: from here on the chunk's pages come from the reference's own functions reading this transport - the
+	// caller's reader for a chunk the GPU never saw, a reader over the chunk's bytes in memory for one handed over part way
+	cpu *thrift.TBufferedTransport
 
 	path    []string
 	repType parquet.FieldRepetitionType
 	schema  *parquet.SchemaElement
 	codec   parquet.CompressionCodec
+	colMeta *parquet.ColumnMetaData
 }
 
 var (
-	pagers     sync.Map // uintptr(thrift reader) -> *chunkPager
-	rawPages   sync.Map // uintptr(*Page handed out by ReadPageRawData) -> rawRef
-	handlePool sync.Pool
-	gpuDevice  = func() int { d, _ := strconv.Atoi(os.Getenv("PQD_DEVICE")); return d }()
+	pagers      sync.Map // uintptr(thrift reader) -> *chunkPager
+	rawPages    sync.Map // uintptr(*Page handed out by ReadPageRawData) -> rawRef
+	freeHandles = make(chan *pqdecode.Handle, maxFreeHandles)
+	gpuDevice   = func() int { d, _ := strconv.Atoi(os.Getenv("PQD_DEVICE")); return d }()
 )
+
+// Handles kept for reuse (each holds a HIP stream, grow-only device buffers and two page-locked staging buffers, none
+// of which the Go collector sees): at most this many wait here, the rest are closed when their chunk is done.
+const maxFreeHandles = 16
 
 type rawRef struct {
 	pg    *chunkPager
@@ -91,10 +114,31 @@ type rawRef struct {
 }
 
 func takeHandle() (*pqdecode.Handle, error) {
-	if h, ok := handlePool.Get().(*pqdecode.Handle); ok && h != nil {
+	select {
+	case h := <-freeHandles:
 		return h, nil
+	default:
+		return pqdecode.NewHandle(gpuDevice) // (carries a finalizer that closes it, as a backstop)
 	}
-	return pqdecode.NewHandle(gpuDevice)
+}
+
+func putHandle(h *pqdecode.Handle) {
+	select {
+	case freeHandles <- h:
+	default:
+		h.Close()
+	}
+}
+
+// delegable: codes on which the reference behaves in a way the typed GPU result cannot express (or simply fails in its
+// own words); the chunk is handed to the reference's own functions from the failing page on, so the caller sees exactly
+// what the reference does.
+func delegable(status int) bool {
+	switch status {
+	case pqdecode.ErrUnsupportedEncoding, pqdecode.ErrUnsupportedType, pqdecode.ErrBitWidth, pqdecode.ErrNoDictionary, pqdecode.ErrRefused:
+		return true
+	}
+	return false
 }
 
 // pagerFor returns the hand-out state of the chunk the thrift reader is positioned in, reading the chunk on the
@@ -105,8 +149,19 @@ func pagerFor(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 	if p, ok := pagers.Load(key); ok {
 		return p.(*chunkPager), nil
 	}
+	// the map must not keep the reader alive: it is keyed by address, and the entry goes when the reader does
+	register := func(pg *chunkPager) {
+		pagers.Store(key, pg)
+		runtime.SetFinalizer(thriftReader, func(t *thrift.TBufferedTransport) {
+			pagers.Delete(uintptr(unsafe.Pointer(t)))
+			pg.release(false)
+		})
+	}
 	if colMetaData.GetCodec() != parquet.CompressionCodec_UNCOMPRESSED {
-		return nil, fmt.Errorf("pqdecode: only UNCOMPRESSED column chunks are decoded on the GPU")
+		// compressed pages are decompressed and decoded by the reference's own code (layout/page.go:753-758, :780-783)
+		pg := &chunkPager{cpu: thriftReader, dictIdx: -1}
+		register(pg)
+		return pg, nil
 	}
 	h, err := takeHandle()
 	if err != nil {
@@ -114,12 +169,12 @@ func pagerFor(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 	}
 	buf, err := h.InputBuffer(int(colMetaData.GetTotalCompressedSize()))
 	if err != nil {
-		handlePool.Put(h)
+		putHandle(h)
 		return nil, err
 	}
 	n, err := io.ReadFull(thriftReader, buf)
 	if n == 0 {
-		handlePool.Put(h)
+		putHandle(h)
 		if err == nil {
 			err = io.EOF
 		}
@@ -128,7 +183,7 @@ func pagerFor(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 	buf = buf[:n] // a chunk cut short by the end of the file: the page that runs past it fails, not the chunk
 	descs, err := pqdecode.ScanPages(buf, colMetaData.GetNumValues())
 	if err != nil && len(descs) == 0 {
-		handlePool.Put(h)
+		putHandle(h)
 		return nil, err
 	}
 	path := append([]string{schemaHandler.GetRootInName()}, colMetaData.GetPathInSchema()...)
@@ -137,20 +192,82 @@ func pagerFor(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 	maxRep, _ := schemaHandler.MaxRepetitionLevel(path)
 	el := schemaHandler.SchemaElements[schemaHandler.MapIndex[name]]
 	pg := &chunkPager{h: h, chunk: buf, descs: descs, dictIdx: -1, path: path, repType: el.GetRepetitionType(), schema: el,
-		codec: colMetaData.GetCodec(),
+		codec: colMetaData.GetCodec(), colMeta: colMetaData,
 		col:   pqdecode.Column{Type: colMetaData.GetType(), TypeLength: el.GetTypeLength(), MaxDef: maxDef, MaxRep: maxRep}}
-	pagers.Store(key, pg)
-	// the map must not keep the reader alive: it is keyed by address, and the entry goes when the reader does
-	runtime.SetFinalizer(thriftReader, func(t *thrift.TBufferedTransport) { pg.release(uintptr(unsafe.Pointer(t))) })
+	register(pg)
 	return pg, nil
 }
 
-func (pg *chunkPager) release(key uintptr) {
-	pagers.Delete(key)
-	if pg.h != nil {
-		handlePool.Put(pg.h)
-		pg.h = nil
+// release hands the chunk's handle back: when the chunk's last page has been handed out, when it goes over to the CPU
+// functions, and (backstop) when the reader is collected.  keepBytes: pages handed out raw may still ask for their
+// values (GetValueFromRawData), so the chunk's bytes are copied out of the handle's page-locked buffer first; such a
+// call then borrows a handle for its own duration.
+func (pg *chunkPager) release(keepBytes bool) {
+	if pg.h == nil {
+		return
 	}
+	if keepBytes {
+		pg.chunk = append([]byte(nil), pg.chunk...)
+	} else {
+		pg.chunk = nil
+	}
+	putHandle(pg.h)
+	pg.h = nil
+}
+
+// headerOffset: where the header of page k starts in the chunk (the end of the page before it).
+func (pg *chunkPager) headerOffset(k int) int64 {
+	if k == 0 {
+		return 0
+	}
+	return pg.descs[k-1].Offset() + int64(pg.descs[k-1].Length())
+}
+
+func memReader(b []byte) *thrift.TBufferedTransport {
+	return thrift.NewTBufferedTransport(thrift.NewStreamTransportR(bytes.NewReader(b)), 4096)
+}
+
+// toCPU hands the chunk over to the reference's functions from page k on: they read a copy of the chunk's bytes from
+// that page's header.  A dictionary page handed out earlier went out with an empty table (its entries were used on the
+// device); the pages the CPU decodes look their values up in it (Page.Decode, layout/page.go:139-164), so it is decoded
+// now and filled in.
+func (pg *chunkPager) toCPU(k int, schemaHandler *schema.SchemaHandler, colMetaData *parquet.ColumnMetaData) error {
+	if pg.dictIdx >= 0 && pg.dictPage != nil {
+		d, _, _, err := readPageCPU(memReader(pg.chunk[pg.headerOffset(pg.dictIdx):]), schemaHandler, colMetaData)
+		if err != nil {
+			return err
+		}
+		pg.dictPage.DataTable = d.DataTable
+	}
+	rest := append([]byte(nil), pg.chunk[pg.headerOffset(k):]...)
+	pg.cpu = memReader(rest)
+	pg.release(pg.rawOut > 0)
+	return nil
+}
+
+// rawToCPU turns a page handed out by ReadPageRawData into the page the reference's ReadPageRawData would have handed
+// out (header, compressed bytes and all), read from the chunk's bytes; the reference's two methods take it from there.
+// The dictionary page the caller holds is filled in as in toCPU.
+func (pg *chunkPager) rawToCPU(p *Page, k int, schemaHandler *schema.SchemaHandler) error {
+	if pg.chunk == nil {
+		return fmt.Errorf("pqdecode: the chunk's bytes have been released")
+	}
+	if pg.dictIdx >= 0 && pg.dictPage != nil && pg.dictPage.DataTable != nil && len(pg.dictPage.DataTable.Values) == 0 {
+		d, _, _, err := readPageCPU(memReader(pg.chunk[pg.headerOffset(pg.dictIdx):]), schemaHandler, pg.colMeta)
+		if err != nil {
+			return err
+		}
+		pg.dictPage.DataTable = d.DataTable
+	}
+	q, err := readPageRawDataCPU(memReader(pg.chunk[pg.headerOffset(k):]), schemaHandler, pg.colMeta)
+	if err != nil {
+		return err
+	}
+	if _, ok := rawPages.LoadAndDelete(uintptr(unsafe.Pointer(p))); ok {
+		pg.rawOut--
+	}
+	*p = *q
+	return nil
 }
 
 // call decodes the pages [first, last), behind the dictionary page in effect when there is one.
@@ -161,7 +278,18 @@ func (pg *chunkPager) call(first, last int, levelsOnly bool) (*pqdecode.Result, 
 		lead = 1
 		descs = append([]pqdecode.PageDesc{pg.descs[pg.dictIdx]}, descs...)
 	}
-	res, err := pg.h.Decode(pg.chunk, descs, pg.col, levelsOnly)
+	h := pg.h
+	if h == nil { // the chunk's handle has gone back already (a raw page asking for its values late): borrow one
+		if pg.chunk == nil {
+			return nil, 0, fmt.Errorf("pqdecode: the chunk's bytes have been released")
+		}
+		var err error
+		if h, err = takeHandle(); err != nil {
+			return nil, 0, err
+		}
+		defer putHandle(h)
+	}
+	res, err := h.Decode(pg.chunk, descs, pg.col, levelsOnly)
 	return res, lead, err
 }
 
@@ -178,7 +306,7 @@ func (pg *chunkPager) decodeFrom(k int, levelsOnly bool) error {
 		if lead == 1 && res.BadPage == 0 {
 			bad = k // the dictionary page handed out earlier failed: the next page meets it
 		}
-		perr = &pageError{bad, pqdecode.Err(res.Status, bad)}
+		perr = &pageError{bad, pqdecode.Err(res.Status, bad), res.Status}
 		last = bad
 		if last > k {
 			if res, lead, err = pg.call(k, last, levelsOnly); err != nil {
@@ -259,6 +387,15 @@ func (pg *chunkPager) newPage(k int) *Page {
 
 func failed(e *pageError, k int) bool { return e != nil && k >= e.page }
 
+// ReleaseReader drops what this file keeps for a thrift reader (its chunk's handle, bytes and results) at once instead of
+// when the reader is collected.  Optional: reader/columnbuffer.go does not call it and need not.
+func ReleaseReader(thriftReader *thrift.TBufferedTransport) {
+	key := uintptr(unsafe.Pointer(thriftReader))
+	if p, ok := pagers.LoadAndDelete(key); ok {
+		p.(*chunkPager).release(false)
+	}
+}
+
 // ReadPage hands out the next page of the chunk: (page, numValues, numRows, err) as layout/page.go:721-937 returns
 // them.  A dictionary page comes back with an empty table (its entries are used on the device) and zeros.
 func ReadPage(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.SchemaHandler, colMetaData *parquet.ColumnMetaData) (*Page, int64, int64, error) {
@@ -266,8 +403,12 @@ func ReadPage(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 	if err != nil {
 		return nil, 0, 0, err
 	}
+	if pg.cpu != nil {
+		return readPageCPU(pg.cpu, schemaHandler, colMetaData)
+	}
 	k := pg.cursor
 	if k >= len(pg.descs) {
+		pg.release(pg.rawOut > 0)
 		return nil, 0, 0, io.EOF
 	}
 	switch pg.descs[k].PageType() {
@@ -283,17 +424,28 @@ func ReadPage(thriftReader *thrift.TBufferedTransport, schemaHandler *schema.Sch
 		}
 	}
 	if failed(pg.errFull, k) {
+		if delegable(pg.errFull.status) {
+			// the reference decodes (or refuses) this page in its own way: from here on the chunk is its own
+			if err = pg.toCPU(k, schemaHandler, colMetaData); err != nil {
+				return nil, 0, 0, err
+			}
+			return readPageCPU(pg.cpu, schemaHandler, colMetaData)
+		}
 		return nil, 0, 0, pg.errFull.err
 	}
 	pg.cursor++
 	page := pg.newPage(k)
 	if pg.descs[k].PageType() == parquet.PageType_DICTIONARY_PAGE {
-		pg.dictIdx = k
+		pg.dictIdx, pg.dictPage = k, page
 		page.DataTable = &Table{Path: pg.path}
 		return page, 0, 0, nil
 	}
 	var numValues, numRows int64
 	page.DataTable, numValues, numRows = pg.table(pg.full, k, true)
+	if pg.cursor == len(pg.descs) {
+		// the chunk's last page: its table lives in Go memory, so the handle can serve another chunk right away
+		pg.release(pg.rawOut > 0)
+	}
 	return page, numValues, numRows, nil
 }
 
@@ -304,8 +456,12 @@ func ReadPageRawData(thriftReader *thrift.TBufferedTransport, schemaHandler *sch
 	if err != nil {
 		return nil, err
 	}
+	if pg.cpu != nil {
+		return readPageRawDataCPU(pg.cpu, schemaHandler, colMetaData) // (its pages are not in rawPages: the two methods below pass them on)
+	}
 	k := pg.cursor
 	if k >= len(pg.descs) {
+		pg.release(pg.rawOut > 0)
 		return nil, io.EOF
 	}
 	switch pg.descs[k].PageType() {
@@ -317,6 +473,8 @@ func ReadPageRawData(thriftReader *thrift.TBufferedTransport, schemaHandler *sch
 	page := pg.newPage(k)
 	key := uintptr(unsafe.Pointer(page))
 	rawPages.Store(key, rawRef{pg, k})
+	pg.rawOut++
+	// (the entry is removed when the page's values have been fetched; the finalizer covers pages that are skipped for good)
 	runtime.SetFinalizer(page, func(p *Page) { rawPages.Delete(uintptr(unsafe.Pointer(p))) })
 	return page, nil
 }
@@ -325,11 +483,11 @@ func ReadPageRawData(thriftReader *thrift.TBufferedTransport, schemaHandler *sch
 func (p *Page) GetRLDLFromRawData(schemaHandler *schema.SchemaHandler) (int64, int64, error) {
 	ref, ok := rawPages.Load(uintptr(unsafe.Pointer(p)))
 	if !ok {
-		return 0, 0, fmt.Errorf("pqdecode: page was not handed out by ReadPageRawData")
+		return p.getRLDLFromRawDataCPU(schemaHandler) // a page of a chunk the CPU functions read
 	}
 	pg, k := ref.(rawRef).pg, ref.(rawRef).index
 	if pg.descs[k].PageType() == parquet.PageType_DICTIONARY_PAGE {
-		pg.dictIdx = k // ReadPageForSkip keeps it as DictPage (reader/columnbuffer.go:170-174)
+		pg.dictIdx, pg.dictPage = k, p // ReadPageForSkip keeps it as DictPage (reader/columnbuffer.go:170-174)
 		p.DataTable = &Table{Path: pg.path}
 		return 0, 0, nil
 	}
@@ -339,6 +497,12 @@ func (p *Page) GetRLDLFromRawData(schemaHandler *schema.SchemaHandler) (int64, i
 		}
 	}
 	if failed(pg.errLevel, k) {
+		if delegable(pg.errLevel.status) {
+			if err := pg.rawToCPU(p, k, schemaHandler); err != nil {
+				return 0, 0, err
+			}
+			return p.getRLDLFromRawDataCPU(schemaHandler)
+		}
 		return 0, 0, pg.errLevel.err
 	}
 	var numValues, numRows int64
@@ -351,9 +515,11 @@ func (p *Page) GetRLDLFromRawData(schemaHandler *schema.SchemaHandler) (int64, i
 func (p *Page) GetValueFromRawData(schemaHandler *schema.SchemaHandler) error {
 	ref, ok := rawPages.Load(uintptr(unsafe.Pointer(p)))
 	if !ok {
-		return fmt.Errorf("pqdecode: page was not handed out by ReadPageRawData")
+		return p.getValueFromRawDataCPU(schemaHandler)
 	}
 	pg, k := ref.(rawRef).pg, ref.(rawRef).index
+	rawPages.Delete(uintptr(unsafe.Pointer(p)))
+	pg.rawOut--
 	if pg.descs[k].PageType() == parquet.PageType_DICTIONARY_PAGE {
 		return nil // its entries are decoded with the data pages that use them
 	}
@@ -364,6 +530,24 @@ func (p *Page) GetValueFromRawData(schemaHandler *schema.SchemaHandler) error {
 			return err
 		}
 		if res.Status != 0 {
+			if delegable(res.Status) {
+				// the page as the reference reads it, its levels decoded once more by the reference's code, then its values
+				keep := p.DataTable
+				if err := pg.rawToCPU(p, k, schemaHandler); err != nil {
+					return err
+				}
+				if _, _, err := p.getRLDLFromRawDataCPU(schemaHandler); err != nil {
+					return err
+				}
+				if err := p.getValueFromRawDataCPU(schemaHandler); err != nil {
+					return err
+				}
+				if keep != nil { // the table the caller has merged its levels from stays the page's table
+					keep.Values = p.DataTable.Values
+					p.DataTable = keep
+				}
+				return nil
+			}
 			return pqdecode.Err(res.Status, k)
 		}
 		d = newDecoded(k, k+1, lead, res)

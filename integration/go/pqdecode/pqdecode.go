@@ -20,6 +20,7 @@ import (
 	"fmt"
 	"io"
 	"math"
+	"runtime"
 	"unsafe"
 
 	"github.com/xitongsys/parquet-go/parquet"
@@ -28,15 +29,35 @@ import (
 // Handle is one HIP stream plus device workspaces, used by one goroutine at a time.
 type Handle struct{ h *C.pqd_handle }
 
+// NewHandle: the caller closes the handle when it is done with it (layout keeps a bounded list of them for reuse and
+// closes the rest); the finalizer is a backstop only - a handle holds device and page-locked memory that the Go
+// collector does not see, so waiting for it would let that memory pile up between collections.
 func NewHandle(device int) (*Handle, error) {
 	var h *C.pqd_handle
 	if rc := C.pqd_handle_create(C.int(device), nil, &h); rc != 0 {
 		return nil, Err(int(rc), -1)
 	}
-	return &Handle{h}, nil
+	hd := &Handle{h}
+	runtime.SetFinalizer(hd, (*Handle).Close)
+	return hd, nil
 }
 
-func (h *Handle) Close() { C.pqd_handle_destroy(h.h); h.h = nil }
+// Close destroys the handle (stream, device buffers, page-locked staging); calling it again does nothing.
+func (h *Handle) Close() {
+	if h.h != nil {
+		C.pqd_handle_destroy(h.h)
+		h.h = nil
+	}
+}
+
+// The library's codes that layout tests for (include/pqdecode.h).
+const (
+	ErrUnsupportedEncoding = int(C.PQD_ERR_UNSUPPORTED_ENCODING)
+	ErrUnsupportedType     = int(C.PQD_ERR_UNSUPPORTED_TYPE)
+	ErrBitWidth            = int(C.PQD_ERR_BIT_WIDTH)
+	ErrNoDictionary        = int(C.PQD_ERR_NO_DICTIONARY)
+	ErrRefused             = int(C.PQD_ERR_REFUSED)
+)
 
 // Err maps the library's codes onto the errors the reference's callers test for
 // (io.EOF has meaning to ColumnBufferType.ReadPage, reader/columnbuffer.go:110).
@@ -73,6 +94,7 @@ func (d *PageDesc) PageType() parquet.PageType { return parquet.PageType(d.page_
 func (d *PageDesc) Encoding() parquet.Encoding { return parquet.Encoding(d.encoding) }
 func (d *PageDesc) NumValues() int32          { return int32(d.num_values) }
 func (d *PageDesc) Length() int32             { return int32(d.length) }
+func (d *PageDesc) Offset() int64             { return int64(d.offset) } // of the page's body, from the start of the chunk
 
 // ScanPages walks the page headers of a chunk (pqd_scan_pages; layout.ReadPageHeader, layout/page.go:625-630), growing
 // the descriptor array when the chunk holds more pages than it has room for.

@@ -15,6 +15,13 @@ reader/columnbuffer.go in the Go binding (integration/go/layout_gpu) - keeps its
 
 ChunkPager stands for the thrift reader positioned inside one column chunk (the reference creates one per row group,
 reader/columnbuffer.go:99): the state of the hand-out is keyed by it.
+
+Chunks the GPU path does not take go to the host's own page functions (`cpu_route`; in the Go binding the reference's
+ReadPage / ReadPageRawData under private names): compressed chunks - the reference's writer compresses with SNAPPY unless
+told otherwise, writer/writer.go:63-65, and reads such pages through compress.Uncompress, layout/page.go:753-758,
+:780-783 - from their first page, and chunks holding a page the library answers with an unsupported-encoding, unsupported-
+type, bit-width, no-dictionary or refused code from that page on.  Nothing in this package decodes pages on the CPU: the
+route is the caller's.
 """
 import numpy as np
 
@@ -74,12 +81,35 @@ class _Decoded(object):
         self.slot0 = np.concatenate([[0], np.cumsum(counts[:, 2])]).astype(np.int64)
 
 
+UNCOMPRESSED = 0                            # parquet.CompressionCodec_UNCOMPRESSED
+# codes on which the chunk goes over to the caller's CPU route from the failing page on: PQD_ERR_UNSUPPORTED_ENCODING,
+# PQD_ERR_UNSUPPORTED_TYPE, PQD_ERR_BIT_WIDTH, PQD_ERR_NO_DICTIONARY, PQD_ERR_REFUSED (include/pqdecode.h)
+DELEGABLE = (-4, -6, -7, -11, -13)
+
+
 class ChunkPager(object):
-    def __init__(self, decoder, chunk_bytes, physical_type, type_length=0, max_def=0, max_rep=0, total_values=-1):
+    def __init__(self, decoder, chunk_bytes, physical_type, type_length=0, max_def=0, max_rep=0, total_values=-1, codec=UNCOMPRESSED,
+                 cpu_route=None):
+        """cpu_route(chunk_bytes, header_offset, dict_header_offset) -> an object with read_page() / read_page_raw_data()
+        (the layout surface over the pages from header_offset on; dict_header_offset: where the header of the dictionary page
+        in effect starts, or None) and, when dict_header_offset is given, read_dictionary() -> the table of that page."""
         self.dec = decoder
         self.chunk = np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes
         self.col = (physical_type, type_length, max_def, max_rep)
         self.is_bytes = physical_type == B.BYTE_ARRAY
+        self.cpu_route = cpu_route
+        self.cpu = None                     # the CPU route's layout object once the chunk is its own
+        self.dict_page_obj = None           # the dictionary page as the caller holds it
+        if codec != UNCOMPRESSED:
+            # compressed pages are the reference's own business (layout/page.go:753-758, :780-783): the GPU never sees the chunk
+            if cpu_route is None:
+                raise B.DecodeError(-4, 0, "compressed chunk and no CPU route to hand it to")
+            self.cpu = cpu_route(self.chunk, 0, None)
+            self.pages = np.zeros(0, B.PAGE_DESC_DTYPE)
+            self.cursor, self.dict_index = 0, None
+            self._full = self._levels = None
+            self._error = {False: None, True: None}
+            return
         # the page headers, walked on the host once (layout.ReadPageHeader, layout/page.go:625-630)
         self.pages = B.scan_pages(self.chunk, total_values) if self.chunk.size else np.zeros(0, B.PAGE_DESC_DTYPE)
         self.cursor = 0
@@ -132,6 +162,19 @@ class ChunkPager(object):
         if self._failed(k, levels_only):
             raise self._error[levels_only][1]
 
+    def _header_offset(self, k):
+        """Where the header of page k starts in the chunk: the end of the page before it."""
+        return 0 if k == 0 else int(self.pages[k - 1]["offset"] + self.pages[k - 1]["length"])
+
+    def _to_cpu(self, k):
+        """Hands the chunk over to the CPU route from page k on.  A dictionary page handed out earlier went out without a
+        table (its entries were used on the device); the pages the CPU route decodes look their values up in it
+        (Page.Decode, layout/page.go:139-164), so the route decodes it now and the table is filled in."""
+        dict_off = self._header_offset(self.dict_index) if self.dict_index is not None else None
+        self.cpu = self.cpu_route(self.chunk, self._header_offset(k), dict_off)
+        if dict_off is not None and self.dict_page_obj is not None:
+            self.dict_page_obj.data_table = self.cpu.read_dictionary()
+
     def _slice(self, d, k, with_values):
         j = k - d.first
         a, b = int(d.slot0[j]), int(d.slot0[j + 1])
@@ -148,6 +191,8 @@ class ChunkPager(object):
     # ---- the layout surface ----
     def read_page(self):
         """layout.ReadPage -> (page, numValues, numRows).  EOFError stands for io.EOF: no page header left."""
+        if self.cpu is not None:
+            return self.cpu.read_page()
         k = self.cursor
         if k >= len(self.pages):
             raise EOFError("no more pages in the chunk")
@@ -156,16 +201,22 @@ class ChunkPager(object):
             raise B.DecodeError(-5, k)      # layout/page.go:813-814, :933-935
         if not self._covered(self._full, k) and not self._failed(k, False):
             self._decode_from(k, False)
+        if self._failed(k, False) and self._error[False][1].code in DELEGABLE and self.cpu_route is not None:
+            # the reference decodes (or refuses) this page in its own way: from here on the chunk is the CPU route's
+            self._to_cpu(k)
+            return self.cpu.read_page()
         self._check_error(k, False)
         self.cursor += 1
         if page.page_type == B.DICTIONARY_PAGE:
-            self.dict_index = k
+            self.dict_index, self.dict_page_obj = k, page
             return page, 0, 0
         page.data_table, n, rows = self._slice(self._full, k, True)
         return page, n, rows
 
     def read_page_raw_data(self):
         """layout.ReadPageRawData: the page as it is in the file; nothing decoded yet."""
+        if self.cpu is not None:
+            return self.cpu.read_page_raw_data()
         k = self.cursor
         if k >= len(self.pages):
             raise EOFError("no more pages in the chunk")

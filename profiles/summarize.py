@@ -85,6 +85,60 @@ def main():
                    "fetch_size_kb": round(fm, 1), "write_size_kb": round(wm, 1), "launches": tot["FETCH_SIZE"][0],
                    "values_per_gpu": cfg.get("values_per_gpu"), "page_values": cfg.get("page_values"), "widths": cfg.get("widths"),
                    "source": tag + "_pmc.csv"}, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+    # ---- serialized launches ----
+    for f in find(os.path.join(out, "kt_serial"), "kernel_stats.csv"):
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(here, tag + "_kernel_stats_serial.csv"), "w", newline="") as g:
+            csv.writer(g).writerows(rows)
+        break
+    # ---- counters of the other encodings: HBM bytes per decode call and per kernel ----
+    extras = {}
+    with open(os.path.join(here, tag + "_pmc_extras.csv"), "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(["workload", "kernel", "launches_per_call", "mean_FETCH_SIZE_KB", "mean_WRITE_SIZE_KB", "hbm_bytes_per_call(2*F+W)"])
+        for d in sorted(glob.glob(os.path.join(out, "ex_*"))):
+            if not os.path.isdir(d):
+                continue
+            name = os.path.basename(d)[3:]
+            per = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+            for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+                for f in find(os.path.join(d, sub), "counter_collection.csv"):
+                    for r in csv.DictReader(open(f)):
+                        if r["Counter_Name"] == ctr:
+                            e = per[short(r["Kernel_Name"])][ctr]
+                            e[0] += 1
+                            e[1] += float(r["Counter_Value"])
+            calls = max(1, max((v["FETCH_SIZE"][0] for k, v in per.items() if "k_collect_status" in k), default=1))
+            total = 0
+            for k, v in sorted(per.items()):
+                f_n, f_v = v.get("FETCH_SIZE", [0, 0.0])
+                w_n, w_v = v.get("WRITE_SIZE", [0, 0.0])
+                b = int((2 * f_v + w_v) * 1024 / calls)
+                total += b
+                w.writerow([name, k, round(max(f_n, w_n) / calls, 2), round(f_v / max(f_n, 1), 1), round(w_v / max(w_n, 1), 1), b])
+            try:
+                res = json.loads(open(os.path.join(out, "ex_%s.fetch.json" % name)).read().strip().splitlines()[-1])["extra"][name]
+            except Exception:
+                res = {}
+            extras[name] = {"traffic": total, "calls": calls, "in_bytes": res.get("in_bytes"), "out_bytes": res.get("out_bytes"),
+                            "workload": res.get("workload")}
+    tj = os.path.join(here, "traffic.json")
+    try:
+        t = json.load(open(tj))
+    except Exception:
+        t = {}
+    t["extras"] = extras
+    t["extras_unit"] = "HBM bytes per decode call (2*FETCH_SIZE + WRITE_SIZE over all kernels of the call), " + tag + "_pmc_extras.csv"
+    json.dump(t, open(tj, "w"), indent=1)
+    # ---- the headline at 4 hardware queues ----
+    try:
+        r4 = json.loads(open(os.path.join(out, "bench_4_queues.json")).read().strip().splitlines()[-1])
+        r16 = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        json.dump({"hw_queues_4": {"value": r4["value"], "ms_per_step": r4["ms_per_step"], "frac": r4["roofline"]["frac"]},
+                   "hw_queues_16_under_rocprof": {"value": r16["value"], "ms_per_step": r16["ms_per_step"], "frac": r16["roofline"]["frac"]}},
+                  open(os.path.join(here, tag + "_queues.json"), "w"), indent=1)
+    except Exception as ex:
+        print("no queue comparison:", ex)
     print("summaries written to", here)
 
 
