@@ -134,7 +134,8 @@ enum {
   PQD_OPT_PRESCAN = 0,        /* run-header walk: 0 a wavefront per stream, 1 a workgroup per stream */
   PQD_OPT_DIRECT_RLE = 1,     /* 0 / 1: expansion of RLE-only pages straight from the page */
   PQD_OPT_JUMP = 2,           /* 0 / 1: spans of short runs resolved by all lanes at once */
-  PQD_OPT_PLAIN_SCATTER = 3,  /* 0 / 1: nullable PLAIN columns scattered straight from the pages */
+  PQD_OPT_PLAIN_SCATTER = 3,  /* 0 / 1 / 2: nullable PLAIN columns scattered straight from the pages (0: through a dense copy); 1: by the validity
+                                 bits the level expansion leaves where it can, 2: always by reading the definition levels again */
   PQD_OPT_SPLIT = 4,          /* 0 / 1: head of a mid-size dictionary kept in LDS */
   PQD_OPT_POISON = 5,         /* 1: every work and output buffer is filled with 0xFF before each call (debugging aid) */
   PQD_OPT_DELTA_BLOCKS = 6,   /* 0 / 1 / 2: DELTA_BINARY_PACKED streams decoded block-parallel (0: a wavefront per page); 2: the block headers of

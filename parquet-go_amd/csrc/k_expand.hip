@@ -35,7 +35,14 @@ struct ExpandArgs {
   uint8_t *values_out;
   TileDesc *descs;             // n_tiles entries, written by k_tile_desc
   const int32_t *work_flag;    // not null: the launch has work only if this word is set (every stream may have been expanded already)
+  // levels: which slots of every definition-level tile hold a value (def == max_def), one bit per slot (128 words per tile,
+  // tile = index among the definition-level tiles), and how many; nullptr: not wanted
+  uint32_t *valid_bits;
+  int32_t *valid_cnt;          // zero when the launch starts
+  int32_t def_tile0;           // index of the first definition-level tile among the tiles of the launch
 };
+
+constexpr int kBitsBytes = kTile / 8;   // LDS of a tile's validity bits (levels only)
 
 __host__ __device__ inline int runs_lds_bytes(int runs_cap) { return (runs_cap + 3) * (int)sizeof(RunEntry); }
 __host__ __device__ inline int marks_lds_bytes(int mark_cap) { return (mark_cap * 2 + 15) / 16 * 16; }
@@ -206,7 +213,7 @@ template <int MODE, int DMODE, int GT, int W>
 __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc &d, const RunEntry *s_runs,
                                              const int *s_seg, uint16_t *s_mark, const uint32_t *s_stage,
                                              const uint8_t *s_dict, int gtid, uint32_t staged, int &n_flag,
-                                             bool &bad_index) {
+                                             bool &bad_index, uint32_t *s_bits) {
   const ChunkCtx &c = a.c;
   const int lane = gtid & 63;
   const int tn = d.t1 - d.t0;
@@ -253,10 +260,21 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
 
       if (MODE == 0) {
         const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+        uint32_t eq = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          n_flag += (j >= j0 && j < j1) && (is_def ? (x[j] != cmp) : (x[j] == cmp));
+          const bool in = j >= j0 && j < j1;
+          n_flag += in && (is_def ? (x[j] != cmp) : (x[j] == cmp));
+          eq |= (in && x[j] == cmp) ? 1u << j : 0u;
           out4[j] = x[j];
+        }
+        if (s_bits && is_def && j1 > j0) {
+          // the item's slots that hold a value, at their places in the tile's bitmap
+          const uint32_t b0 = (uint32_t)(vrel + j0), mm = eq >> j0, sh = b0 & 31u;
+          if (mm) {
+            atomicOr(&s_bits[b0 >> 5], mm << sh);
+            if (sh > 24u && (mm >> (32u - sh)) != 0u) atomicOr(&s_bits[(b0 >> 5) + 1u], mm >> (32u - sh));
+          }
         }
       } else if (MODE == 4 || MODE == 8) {
         if (ident) {
@@ -314,7 +332,8 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
 // from global memory): the items, then the tile's counts or its error.
 template <int MODE, int DMODE, int GT>
 __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc &d, const RunEntry *s_runs, const int *s_seg,
-                                             uint16_t *s_mark, const uint32_t *s_stage, const uint8_t *s_dict, int gtid) {
+                                             uint16_t *s_mark, const uint32_t *s_stage, const uint8_t *s_dict, int gtid, uint32_t *s_bits,
+                                             int tile) {
   const ChunkCtx &c = a.c;
   const int esz = c.elem_size;
   const bool valid = (d.flags & 1) != 0;
@@ -326,7 +345,7 @@ __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc
   bool bad_index = false;
   if (in_lds) {
     switch (__builtin_amdgcn_readfirstlane(d.w)) {
-#define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index); break;
+#define PQD_CASE(W) case W: expand_items<MODE, DMODE, GT, W>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, staged, n_flag, bad_index, s_bits); break;
       PQD_CASE(0) PQD_CASE(1) PQD_CASE(2) PQD_CASE(3) PQD_CASE(4) PQD_CASE(5) PQD_CASE(6) PQD_CASE(7) PQD_CASE(8)
       PQD_CASE(9) PQD_CASE(10) PQD_CASE(11) PQD_CASE(12) PQD_CASE(13) PQD_CASE(14) PQD_CASE(15) PQD_CASE(16)
       PQD_CASE(17) PQD_CASE(18) PQD_CASE(19) PQD_CASE(20) PQD_CASE(21) PQD_CASE(22) PQD_CASE(23) PQD_CASE(24)
@@ -350,6 +369,7 @@ __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc
         for (int j = 0; j < n4; j++) {
           n_flag += is_def ? (x[j] != cmp) : (x[j] == cmp);
           outp[j] = (int32_t)x[j];
+          if (s_bits && is_def && x[j] == cmp) atomicOr(&s_bits[(uint32_t)(rel + j) >> 5], 1u << ((uint32_t)(rel + j) & 31u));
         }
       } else {
         for (int j = 0; j < n4; j++) {
@@ -373,6 +393,21 @@ __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc
     // wave reduction, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) n_flag += __shfl_down(n_flag, o);
     if ((gtid & 63) == 0 && n_flag) atomicAdd((d.flags & 4) ? &c.state[d.page].n_nulls : &c.state[d.page].n_rows, n_flag);
+    if (s_bits) {
+      // the tile's validity bits leave for memory (a definition-level tile) and the bitmap is left clean for the next tile
+      __syncthreads();
+      if (gtid < kTile / 32) {
+        const uint32_t b = s_bits[gtid];
+        s_bits[gtid] = 0u;
+        if (tile >= a.def_tile0) {     // (a tile that holds nothing - a failed stream - leaves zeros)
+          const int dt = tile - a.def_tile0;
+          a.valid_bits[(size_t)dt * (kTile / 32) + gtid] = b;
+          int n = __builtin_popcount(b);
+          for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+          if ((gtid & 63) == 0 && n) atomicAdd(&a.valid_cnt[dt], n);
+        }
+      }
+    }
   } else {
     if (bad_index) set_status(&c.state[d.page].status, PQD_ERR_MALFORMED);  // dict.Values[index] out of range
   }
@@ -382,8 +417,8 @@ __device__ __forceinline__ void process_tile(const ExpandArgs &a, const TileDesc
 // two vectors of packed bytes - all there is, for most tiles.  Asked for together, before anything waits: one trip to
 // memory per tile, not one per kind of thing.
 struct TileLoads {
-  RunEntry e0;
-  uint32_t zn0;
+  RunEntry e0, e1;      // run entries gtid and gtid + GT of the slice (level tiles of short runs hold more than GT)
+  uint32_t zn0, zn1;
   uint4 v0, v1;
 };
 
@@ -395,8 +430,8 @@ __device__ __forceinline__ uint4 stage_raw(const TileDesc &d, const uint8_t *sba
 
 template <int GT>
 __device__ __forceinline__ void tile_issue_loads(const ExpandArgs &a, const TileDesc &d, int gtid, TileLoads &pf) {
-  pf.e0 = RunEntry{0u, 0u, 0u, 0u};
-  pf.zn0 = 0;
+  pf.e0 = pf.e1 = RunEntry{0u, 0u, 0u, 0u};
+  pf.zn0 = pf.zn1 = 0;
   pf.v0 = pf.v1 = make_uint4(0, 0, 0, 0);
   if ((d.flags & 2) == 0) return;
   const RunEntry *gruns = a.c.runs + d.run0;
@@ -404,6 +439,8 @@ __device__ __forceinline__ void tile_issue_loads(const ExpandArgs &a, const Tile
   const int nvec = (d.span + 8 + 15) >> 4;
   if (gtid < d.nr) pf.e0 = gruns[gtid];
   if (gtid < d.nr - 1) pf.zn0 = gruns[gtid + 1].z;
+  if (gtid + GT < d.nr) pf.e1 = gruns[gtid + GT];
+  if (gtid + GT < d.nr - 1) pf.zn1 = gruns[gtid + GT + 1].z;
   pf.v0 = stage_raw(d, sbase, nvec, gtid);
   pf.v1 = stage_raw(d, sbase, nvec, gtid + GT);
 }
@@ -447,7 +484,11 @@ __device__ __forceinline__ void tile_stage(const ExpandArgs &a, const TileDesc &
     s_runs[gtid] = pf.e0;
     if (gtid < d.nr - 1) note_run(gtid, pf.e0, pf.zn0);
   }
-  for (int i = gtid + GT; i < d.nr; i += GT) {
+  if (gtid + GT < d.nr) {
+    s_runs[gtid + GT] = pf.e1;
+    if (gtid + GT < d.nr - 1) note_run(gtid + GT, pf.e1, pf.zn1);
+  }
+  for (int i = gtid + 2 * GT; i < d.nr; i += GT) {
     const RunEntry e = gruns[i];
     s_runs[i] = e;
     if (i < d.nr - 1) note_run(i, e, gruns[i + 1].z);
@@ -513,6 +554,9 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
 
   // The tiles of this group: first, first + step, ...  Tile i's descriptor sits in ring slot i % kRingSlots.
   uint32_t *s_ring = reinterpret_cast<uint32_t *>(area + a.group_bytes - kRingSlots * (int)sizeof(TileDesc));
+  // (levels with validity bits wanted: the bitmap sits behind the ring, beyond group_bytes)
+  uint32_t *s_bits = MODE == 0 && a.valid_bits ? reinterpret_cast<uint32_t *>(area + a.group_bytes) : nullptr;
+  if (s_bits) for (int i = gtid; i < kTile / 32; i += GT) s_bits[i] = 0u;
   const int first = a.tile_lo + (int)blockIdx.x * G + g, step = (int)gridDim.x * G;
   const int n_my = first < a.n_tiles ? (a.n_tiles - first + step - 1) / step : 0;
   // (the groups of a workgroup share its barriers: all of them make the rounds of the one with the most tiles)
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(G * GT) void k_hybrid_expand(ExpandArgs a, const Ti
     tile_issue_loads<GT>(a, d1, gtid, pf);
     dn = 0;
     if (gtid < kDescUsed && i + 2 < n_my) dn = desc_words(i + 2)[gtid];
-    process_tile<MODE, DMODE, GT>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid);
+    process_tile<MODE, DMODE, GT>(a, d, s_runs, s_seg, s_mark, s_stage, s_dict, gtid, s_bits, i < n_my ? first + i * step : -1);
   }
 }
 
@@ -579,18 +623,20 @@ static hipError_t launch_expand(K kern, const ExpandArgs &a, int grid, int threa
 
 hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
                                 int stage_bytes, int32_t *rep_out, int32_t *def_out, TileDesc *descs, int n_cu,
-                                hipStream_t stream) {
+                                uint32_t *valid_bits, int32_t *valid_cnt, int def_tile0, hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   ExpandArgs a;
+  a.valid_bits = valid_bits; a.valid_cnt = valid_cnt; a.def_tile0 = def_tile0;
   a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 0; a.tile_lo = 0; a.n_tiles = n_tiles;
   a.rep_out = rep_out; a.def_out = def_out; a.dict = nullptr; a.dict_n = 0; a.no_dict = 0; a.dict_lds_n = 0; a.dict_lds_bytes = 0;
   a.values_out = nullptr; a.descs = descs; a.work_flag = nullptr;
   set_group_layout(a, kRunSlice, stage_bytes);
-  int per_cu = kLdsTotal / (a.group_bytes + 512);
+  const int lds = a.group_bytes + (valid_bits ? kBitsBytes : 0);
+  int per_cu = kLdsTotal / (lds + 512);
   if (per_cu > 8) per_cu = 8;
   int grid = n_cu * per_cu;
   if (grid > n_tiles) grid = n_tiles;
-  return launch_expand(&k_hybrid_expand<0, 0, 1, 256>, a, grid, 256, (size_t)a.group_bytes, stream);
+  return launch_expand(&k_hybrid_expand<0, 0, 1, 256>, a, grid, 256, (size_t)lds, stream);
 }
 
 hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int tile_lo, int tile_hi,
@@ -601,6 +647,7 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
   ExpandArgs a;
   a.c = c; a.tile_prefix = tile_prefix; a.tile_stream = tile_stream; a.stream0 = 2 * c.nd; a.tile_lo = tile_lo; a.n_tiles = tile_hi;
   a.no_dict = dict_n < 0;
+  a.valid_bits = nullptr; a.valid_cnt = nullptr; a.def_tile0 = 0;
   if (dict_n < 0) dict_n = 0;
   a.rep_out = nullptr; a.def_out = nullptr; a.dict = dict; a.dict_n = dict_n; a.values_out = values_out; a.descs = descs;
   a.work_flag = c.chunk_status + kWorkFlag;

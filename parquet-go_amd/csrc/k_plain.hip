@@ -437,6 +437,104 @@ __global__ __launch_bounds__(256) void k_scatter_apply_plain(ChunkCtx c, const i
   }
 }
 
+// ---- the same from validity bits: the level expansion leaves, per definition-level tile (kScatterTile slots of one page), a
+// bit per slot that holds a value and their number, so the levels are not read again: counts -> exclusive scan -> every
+// thread takes 16 slots (one half word of bits), ranks by popcount, values from the page ----
+static_assert(kScatterTile == kTile, "scatter tiles are the level expansion's tiles");
+
+__global__ __launch_bounds__(1024) void k_scatter_scan_cnt(const int32_t *cnt, int64_t *partial, int n_tiles) {
+  // one workgroup: every thread adds up a stretch of consecutive counts, the stretches' sums are scanned (wave scans, then
+  // the sixteen wave totals), and every thread writes the exclusive prefixes of its stretch
+  __shared__ int64_t s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (n_tiles + 1023) / 1024;
+  const int lo = tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  int64_t sum = 0;
+  for (int t = lo; t < hi; t++) sum += cnt[t];
+  int64_t incl = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  int64_t base = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) { if (q < wv) base += s_w[q]; total += s_w[q]; }
+  int64_t run = base + incl - sum;
+  for (int t = lo; t < hi; t++) { partial[t] = run; run += cnt[t]; }
+  if (tid == 0) partial[n_tiles] = total;
+}
+
+// A workgroup takes a tile, a wavefront 1024 of its slots (32 words of bits): lane l holds the popcount of word l, a wave
+// scan gives every word its rank, and the wavefront then walks its slots 64 at a time - lane l takes slot 64 j + l - so that
+// neighbouring lanes read neighbouring values from the page and write neighbouring slots.
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_scatter_bits_plain(ChunkCtx c, const int32_t *__restrict__ tile_prefix, const int32_t *__restrict__ tile_stream,
+                                                            int def_tile0, const uint32_t *__restrict__ bits, const int64_t *__restrict__ partial,
+                                                            uint8_t *out) {
+  typedef typename std::conditional<ESZ == 8, uint64_t, uint32_t>::type T;
+  struct TU { T v; } __attribute__((packed));
+  __shared__ int s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dt = blockIdx.x;
+  const int ls = tile_stream[def_tile0 + dt];            // the definition-level stream (index among the level streams)
+  const Stream *sp = &c.streams[ls];
+  const int p = sp->page;
+  const int first = tile_prefix[ls] - def_tile0;         // the page's first definition-level tile
+  const int t0 = (dt - first) * kScatterTile;
+  const PageState *ps = &c.state[p];
+  if (dt == first && tid == 0 && ps->status == 0 && c.pages[p].encoding == PQD_ENC_PLAIN) {
+    // (the page's length is checked the way the copying kernel does, binaryread.go:12-18)
+    const int st = plain_fixed_status(c.physical_type, ps->val_len, ps->cnt, c.elem_size);
+    if (st) set_status1(&c.state[p].status, st);
+  }
+  const int n = c.pages[p].num_values > 0 ? c.pages[p].num_values : 0;
+  if (t0 >= n) return;
+  const uint32_t word = lane < 32 ? bits[(size_t)dt * (kScatterTile / 32) + wv * 32 + lane] : 0u;
+  const int cw = __builtin_popcount(word);
+  int incl = cw;
+  for (int o = 1; o < 32; o <<= 1) {
+    const int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  const int wave_total = __shfl(incl, 31);
+  if (lane == 0) s_wave[wv] = wave_total;
+  __syncthreads();
+  int wbase = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (q < wv) wbase += s_wave[q];
+  const int excl = incl - cw;                                         // values in the wavefront's words before word `lane`
+  const int64_t r0 = (partial[dt] - partial[first]) + wbase;          // rank, among the page's values, of the wavefront's first
+  const int64_t val_len = ps->val_len;
+  const uint8_t *src = c.in + ps->val_off;
+  T *o = reinterpret_cast<T *>(out) + c.pages[p].slot_base + t0 + wv * 1024;
+  const int left = n - (t0 + wv * 1024);                              // slots of the page from the wavefront's first on
+  const uint32_t below = (1u << (lane & 31)) - 1u;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int wi = 2 * j + (lane >> 5);
+    const uint32_t wj = (uint32_t)__shfl((int)word, wi);
+    const int ej = __shfl(excl, wi);
+    const bool v = (wj >> (lane & 31)) & 1u;
+    const int64_t off = (r0 + ej + __builtin_popcount(wj & below)) * ESZ;
+    // (a page that is too short has failed; its slots only must not be read from beyond it)
+    const T y = (v && off + ESZ <= val_len) ? reinterpret_cast<const TU *>(src + off)->v : (T)0;
+    if (64 * j + lane < left) reinterpret_cast<TU *>(o + 64 * j + lane)->v = y;
+  }
+}
+
+hipError_t launch_scatter_plain_bits(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int def_tile0, int n_def_tiles,
+                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, uint8_t *out, hipStream_t stream) {
+  if (n_def_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_scan_cnt, dim3(1), dim3(1024), 0, stream, valid_cnt, partial, n_def_tiles);
+  if (c.elem_size == 4)
+    hipLaunchKernelGGL(k_scatter_bits_plain<4>, dim3(n_def_tiles), dim3(256), 0, stream, c, tile_prefix, tile_stream, def_tile0, valid_bits, partial, out);
+  else
+    hipLaunchKernelGGL(k_scatter_bits_plain<8>, dim3(n_def_tiles), dim3(256), 0, stream, c, tile_prefix, tile_stream, def_tile0, valid_bits, partial, out);
+  return hipGetLastError();
+}
+
 // ---- row index: out[r] = slot of the r-th entry with repetition level 0 (layout/table.go:73-103 cuts rows there) ----
 __global__ __launch_bounds__(256) void k_row_starts(const int32_t *rep, int64_t n, const int64_t *partial, int64_t *out,
                                                     int64_t n_rows) {

@@ -176,7 +176,7 @@ struct pqd_handle {
 
   DevBuf in, meta, runs, tile_run, tile_desc, dict, values, dense, def, rep, offsets, bytes, scratch, small;
   DevBuf pairs, lens64, prefix64, parent, doff, dict_pairs;  // BYTE_ARRAY work arrays
-  DevBuf row_starts, dba_flags, delta_blocks;
+  DevBuf row_starts, dba_flags, delta_blocks, lvbits;
   int64_t bytes_len = 0;
   HostBuf stage_in[2], stage_out, stage_meta, host_small;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};   // the copy out of stage_in[k] has been done
@@ -208,9 +208,9 @@ struct pqd_handle {
   std::vector<KernelEvent> events;   // pool
   size_t n_events = 0;               // used by the last call
 
-  DevBuf *all_bufs_[23] = {&in, &meta, &runs, &tile_run, &tile_desc, &dict, &values, &dense, &def, &rep, &offsets, &bytes,
+  DevBuf *all_bufs_[24] = {&in, &meta, &runs, &tile_run, &tile_desc, &dict, &values, &dense, &def, &rep, &offsets, &bytes,
                            &scratch, &small, &pairs, &lens64, &prefix64, &parent, &doff, &dict_pairs, &row_starts, &dba_flags,
-                           &delta_blocks};
+                           &delta_blocks, &lvbits};
 };
 
 namespace {
@@ -502,6 +502,17 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   const size_t off_pgsum = align_up(off_streams + sizeof(Stream) * n_streams, 256);
   const size_t meta_bytes = align_up(off_pgsum + 32 * (((size_t)n_pages + 255) / 256 + 1), 256);
 
+  // a nullable column of PLAIN pages only: the scatter takes the values from the pages
+  const bool plain_scatter = !levels_only && col->max_def > 0 && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_rle &&
+                             !any_dlba && !any_dba && host_status == PQD_OK &&
+                             (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
+                              col->physical_type == PQD_DOUBLE) && h->opt[PQD_OPT_PLAIN_SCATTER] != 0;
+  // ... and from the validity bits the level expansion leaves per tile, when every level stream goes through it
+  const int n_def_tiles = col->max_def > 0 ? tp_levels.back() - tp_levels[(size_t)nd] : 0;
+  bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;      // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first
+  if (h->opt[PQD_OPT_DIRECT_RLE] >= 0) direct_rle = h->opt[PQD_OPT_DIRECT_RLE] == 1;
+  const bool scatter_bits = plain_scatter && !direct_rle && n_def_tiles > 0 && h->opt[PQD_OPT_PLAIN_SCATTER] != 2;
+
   // ---- workspaces and outputs (every allocation of the call happens here, before anything is enqueued) ----
   if (h->no_alloc) {
     // carved anew from the arena on every call
@@ -521,7 +532,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   } else if (!is_bytes) {
     if ((slots > 0 || !h->values.fixed) && (rc = h->values.ensure(val_bytes))) return rc;   // (a chunk without slots writes no values: a caller may pass none)
     if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
-    if (nullable && slots > 0 && (rc = h->scratch.ensure(12 * (size_t)((slots + 4095) / 4096) + 64))) return rc;
+    if (nullable && slots > 0 && (rc = h->scratch.ensure(12 * ((size_t)((slots + 4095) / 4096) + (size_t)n_def_tiles) + 128))) return rc;
+    if (scatter_bits && (rc = h->lvbits.ensure((size_t)n_def_tiles * (kTile / 8 + 4) + 64))) return rc;
     if (any_dlba || any_dba) {   // FIXED_LEN_BYTE_ARRAY pages under the delta byte-array encodings: the work arrays of the BYTE_ARRAY path
       const size_t n8 = 8 * ((size_t)slots + 2) + 64;
       if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->lens64.ensure(n8))) return rc;
@@ -637,9 +649,6 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // Level streams of nullable and nested columns are where runs of a few values each are the rule; dictionary
   // indices of low-cardinality columns have them too (the variant costs 6 KiB of LDS per stream).
   const bool jump = h->opt[PQD_OPT_JUMP] != 0;
-  // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first
-  bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;
-  if (h->opt[PQD_OPT_DIRECT_RLE] >= 0) direct_rle = h->opt[PQD_OPT_DIRECT_RLE] == 1;
   // large pages: the index stream of a page walked and expanded by one workgroup, in one pass over its bytes
   constexpr int kFusedMinLen = 16 * 1024;
   bool fused = nd > 0 && data_bytes / nd >= 2 * kFusedMinLen;
@@ -705,8 +714,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
       if (direct_rle) { Prof pf(h, "k_rle_only_pages(levels)"); HIP_TRY(launch_rle_only_levels(c, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
       { Prof pf(h, "k_hybrid_prescan(levels)"); HIP_TRY(launch_hybrid_prescan(c, 0, 2 * nd, wide_levels, jump, h->stream)); }
+      uint32_t *vbits = scatter_bits ? static_cast<uint32_t *>(h->lvbits.p) : nullptr;
+      int32_t *vcnt = scatter_bits ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(h->lvbits.p) + (size_t)n_def_tiles * (kTile / 8)) : nullptr;
+      if (scatter_bits) HIP_TRY(hipMemsetAsync(vcnt, 0, 4 * (size_t)n_def_tiles, h->stream));
       { Prof pf(h, "k_hybrid_expand<levels>");
-        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu, h->stream)); }
+        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
+                                     vbits, vcnt, tp_levels[(size_t)nd], h->stream)); }
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, reinterpret_cast<int64_t *>(mb + off_pgsum), h->stream)); }
@@ -777,10 +790,6 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         if ((rc = expand_dict_groups(c, static_cast<const uint8_t *>(h->dict.p), esz, dense_out))) return rc; }
       HIP_TRY(from_heavy());
     }
-    // a nullable column of PLAIN pages only: the scatter takes the values from the pages
-    const bool plain_scatter = nullable && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_rle && host_status == PQD_OK &&
-                               (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
-                                col->physical_type == PQD_DOUBLE) && h->opt[PQD_OPT_PLAIN_SCATTER] != 0;
     if (any_plain && !plain_scatter) {
       if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
       else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
@@ -822,8 +831,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), dense_out, 1, doff + slots, cap, h->stream)); }
     }
     if (nullable && slots > 0) {
-      Prof pf(h, plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
-      if (plain_scatter)
+      Prof pf(h, scatter_bits ? "k_scatter(plain pages, validity bits)" : plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
+      if (scatter_bits)
+        HIP_TRY(launch_scatter_plain_bits(c, d_tp_lv, d_ts_lv, tp_levels[(size_t)nd], n_def_tiles, static_cast<const uint32_t *>(h->lvbits.p),
+                                          reinterpret_cast<const int32_t *>(static_cast<const uint8_t *>(h->lvbits.p) + (size_t)n_def_tiles * (kTile / 8)),
+                                          static_cast<int64_t *>(h->scratch.p), static_cast<uint8_t *>(h->values.p), h->stream));
+      else if (plain_scatter)
         HIP_TRY(launch_scatter_plain(c, static_cast<const int32_t *>(h->def.p), static_cast<uint8_t *>(h->values.p), slots,
                                      static_cast<int64_t *>(h->scratch.p), h->stream));
       else

@@ -26,9 +26,11 @@ hipError_t launch_page_fused(const ChunkCtx &c, const uint8_t *dict_table, uint8
 hipError_t launch_hybrid_prescan_wide(const ChunkCtx &c, int s0, int n, hipStream_t stream);
 // definition / repetition levels -> int32 arrays (+ null and row counts)
 // stage_bytes: LDS to reserve for the packed bytes of one tile (tiles that need more take a slower path)
+// valid_bits / valid_cnt (or nullptr): per definition-level tile (tiles def_tile0 .. n_tiles of the launch), one bit per slot
+// that holds a value (128 words a tile) and their number (valid_cnt zeroed by the caller)
 hipError_t launch_expand_levels(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int n_tiles,
                                 int stage_bytes, int32_t *rep_out, int32_t *def_out, TileDesc *descs, int n_cu,
-                                hipStream_t stream);
+                                uint32_t *valid_bits, int32_t *valid_cnt, int def_tile0, hipStream_t stream);
 // block_sums: 32 bytes per 256 pages (device work space)
 hipError_t launch_pages_finalize(const ChunkCtx &c, int64_t *totals, int64_t *block_sums, hipStream_t stream);
 hipError_t launch_collect_status(const ChunkCtx &c, int32_t *out, hipStream_t stream);
@@ -58,6 +60,10 @@ hipError_t launch_scatter_fixed(const ChunkCtx &c, const int32_t *def_levels, co
 // (scratch: 12 bytes per 4096 slots + 64)
 hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, uint8_t *out, int64_t n_slots, int64_t *scratch,
                                 hipStream_t stream);
+// the same from the validity bits the level expansion left per definition-level tile: the levels are not read again
+// (tile_prefix / tile_stream: the level tiles' tables; n_def_tiles tiles from def_tile0 on; partial: n_def_tiles + 1 int64)
+hipError_t launch_scatter_plain_bits(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int def_tile0, int n_def_tiles,
+                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, uint8_t *out, hipStream_t stream);
 
 // ---- k_delta.hip ----
 // one wavefront per page whose value encoding is `encoding`; elem_size 4 or 8; src_sel 1 continues at the end of

@@ -15,8 +15,9 @@ from test_gpu_parity import check_same, PHYS_DT
 first, n_seeds = int(sys.argv[1]), int(sys.argv[2])
 B = pq.binding
 decs = []
-for variant in range(4):
+for variant in range(5):
     d = pq.Decoder(0)
+    if variant == 4: d.set_option(B.OPT_PLAIN_SCATTER, 2); d.set_option(B.OPT_DIRECT_RLE, 0)
     if variant == 1: d.set_option(B.OPT_PRESCAN, 0); d.set_option(B.OPT_JUMP, 0)
     if variant == 2: d.set_option(B.OPT_PRESCAN, 1); d.set_option(B.OPT_DIRECT_RLE, 0)
     if variant == 3: d.set_option(B.OPT_PLAIN_SCATTER, 0); d.set_option(B.OPT_JUMP, 1)
@@ -74,10 +75,10 @@ for si in range(n_seeds):
     if os.environ.get("SWEEP_VERBOSE"):
         print("seed %d ptype %d %s levels (%d, %d) %s pages %s" % (seed, ptype, enc, max_def, max_rep, style, desc), flush=True)
     try:
-        g, o = check_same(decs[si % 4], oracle, chunk, pages, ptype, 0, max_def, max_rep)
+        g, o = check_same(decs[si % 5], oracle, chunk, pages, ptype, 0, max_def, max_rep)
         assert o.status == 0, "oracle status %d" % o.status
     except AssertionError as e:
-        fails.append("seed %d variant %d ptype %d %s levels (%d, %d) %s pages %s: %s" % (seed, si % 4, ptype, enc, max_def, max_rep, style, desc, str(e)[:200]))
+        fails.append("seed %d variant %d ptype %d %s levels (%d, %d) %s pages %s: %s" % (seed, si % 5, ptype, enc, max_def, max_rep, style, desc, str(e)[:200]))
     if si % 20 == 19:
         print("%d chunks, %d failures, %.0f s" % (si + 1, len(fails), time.time() - t0), flush=True)
 for f in fails[:30]: print(f)

@@ -658,13 +658,23 @@ def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
     check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
 
 
-@pytest.mark.parametrize("copy_first", ["", "1"])
+@pytest.mark.parametrize("how", ["bits", "levels", "levels-direct", "copy"])
 @pytest.mark.parametrize("ptype", [pg.INT32, pg.INT64, pg.FLOAT, pg.DOUBLE])
-def test_nullable_plain_scattered_from_the_pages(dec, oracle, ptype, copy_first):
+def test_nullable_plain_scattered_from_the_pages(dec, oracle, ptype, how):
     # nullable column, PLAIN pages only: the scatter reads the value sections of the pages (no dense copy): many small
-    # pages per 4096 slots, pages that are all null, pages without slots, a page boundary inside a thread's four
-    # slots; then the same chunk with one page's value section a few bytes short (binaryread.go:12-18: ReadFull fails)
-    if copy_first:
+    # pages per 4096 slots, pages that are all null, pages without slots, a page boundary inside a thread's
+    # slots; then the same chunk with one page's value section a few bytes short (binaryread.go:12-18: ReadFull fails).
+    # Which slots hold a value comes from the validity bits the level expansion leaves per tile ("bits"), or from the
+    # definition levels read again ("levels"; "levels-direct": with the RLE-only level expansion tried first, which
+    # leaves no bits), or the values go through a dense copy first ("copy").
+    if how == "bits":
+        dec.set_option(1, 0)                 # PQD_OPT_DIRECT_RLE off: every level stream through the tile expansion
+    elif how == "levels":
+        dec.set_option(1, 0)
+        dec.set_option(3, 2)                 # PQD_OPT_PLAIN_SCATTER: read the levels again
+    elif how == "levels-direct":
+        dec.set_option(1, 1)
+    else:
         dec.set_option(3, 0)                 # PQD_OPT_PLAIN_SCATTER off
     rng = np.random.default_rng(6100 + ptype)
     esz = np.dtype(PHYS_DT[ptype]).itemsize
