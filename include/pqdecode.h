@@ -141,7 +141,9 @@ enum {
   PQD_OPT_DELTA_BLOCKS = 6,   /* 0 / 1 / 2: DELTA_BINARY_PACKED streams decoded block-parallel (0: a wavefront per page); 2: the block headers of
                                  every stream are walked first, 1: streams whose blocks all look one length long skip that walk */
   PQD_OPT_FUSED = 7,          /* 0 / 1: index streams of large pages walked and expanded by one workgroup per page, in one pass */
-  PQD_OPT_COUNT = 8
+  PQD_OPT_BYTE_OFFSETS = 8,   /* 0 / 1: BYTE_ARRAY output offsets in one pass over the lengths (tiles look back for the sum in front of them), and for
+                                 chunks of DELTA_LENGTH_BYTE_ARRAY pages only straight from the decoded lengths; 0: sums, scan and offsets as three kernels */
+  PQD_OPT_COUNT = 9
 };
 int pqd_set_option(pqd_handle *h, int option, int value);
 

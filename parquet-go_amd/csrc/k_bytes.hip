@@ -71,7 +71,12 @@ __global__ void k_plain_ba_walk(ChunkCtx c, const int32_t *__restrict__ dict_pag
 // lens[dense_base + i]) -> pairs; the bytes of value i start where value i-1 ended, the first at the end of
 // the length stream (PageState.aux0).  One block per data page, running carry.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out) {
+// With page_base / doff given (a chunk of DELTA_LENGTH_BYTE_ARRAY pages only) no pairs are written: the strings of a page
+// follow each other in the output as they do in the page, so value i goes to page_base[d] + (its position - the payload's
+// start), page_base being the payload sizes of the pages in front added up (k_dlba_page_bases).  A page that holds bytes
+// behind its last string makes those sums wrong for every page after it: noted in chunk_status[kLayoutMismatch].
+__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out,
+                                                    const int64_t *__restrict__ page_base, int64_t *__restrict__ doff) {
   constexpr int kPer = 4;  // consecutive values per thread and round
   __shared__ int64_t s_wave[4];
   __shared__ int64_t s_carry;
@@ -83,6 +88,8 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t cnt = ps->cnt, base = ps->dense_base;
   const int64_t end = ps->val_off + ps->val_len;
+  const int64_t pay0 = ps->aux0;
+  const int64_t out0 = doff ? page_base[d] - pay0 : 0;
   if (tid == 0) { s_carry = ps->aux0; s_bad = 0; s_refused = 0; }
   __syncthreads();
   for (int64_t i0 = 0; i0 < cnt; i0 += 256 * kPer) {
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
       const int64_t i = i0 + (int64_t)tid * kPer + j;
       if (i < cnt) {
         if (ln[j] > 0 && src + ln[j] > end) s_refused = 1;  // the reference would zero pad a cut string (or hit EOF at the next one)
-        pairs_out[base + i] = make_pair(src, ln[j]);
+        if (doff) doff[base + i] = out0 + src;
+        else pairs_out[base + i] = make_pair(src, ln[j]);
       }
       src += ln[j];
     }
@@ -120,7 +128,49 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
     if (s_refused) set_status_b(&ps->status, PQD_ERR_REFUSED);
     else if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
     ps->aux1 = s_carry;  // end of the payload
+    if (doff) {
+      doff[base + cnt] = out0 + s_carry;     // (the next page's first offset, or the total)
+      if (s_carry != end && !s_refused && !s_bad) c.chunk_status[kLayoutMismatch] = 1;
+    }
   }
+}
+
+// page_base[d] = payload bytes of the DELTA_LENGTH_BYTE_ARRAY pages in front of data page d (what lies between the end of a
+// page's length stream and the end of the page), page_base[nd] = their total; one workgroup.
+__global__ __launch_bounds__(1024) void k_dlba_page_bases(ChunkCtx c, int64_t *page_base) {
+  __shared__ int64_t s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) c.chunk_status[kLayoutMismatch] = 0;
+  auto payload = [&](int d) -> int64_t {
+    const int p = c.streams[2 * c.nd + d].page;
+    const PageState &ps = c.state[p];
+    if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY || ps.status != 0 || ps.cnt <= 0) return 0;
+    const int64_t n = ps.val_off + ps.val_len - ps.aux0;
+    return n > 0 ? n : 0;
+  };
+  const int per = (c.nd + 1023) / 1024;
+  const int lo = tid * per, hi = lo + per < c.nd ? lo + per : c.nd;
+  int64_t sum = 0;
+  for (int d = lo; d < hi; d++) sum += payload(d);
+  int64_t incl = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  int64_t before = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) { if (q < wv) before += s_w[q]; total += s_w[q]; }
+  int64_t run = before + incl - sum;
+  for (int d = lo; d < hi; d++) { page_base[d] = run; run += payload(d); }
+  if (tid == 0) page_base[c.nd] = total;
+}
+
+// the slots behind the last value repeat the byte total (nullable columns: their dense offsets cover all slots)
+__global__ __launch_bounds__(256) void k_fill_offsets_tail(int64_t *doff, int64_t from, int64_t n_slots, const int64_t *n_dense, const int64_t *total) {
+  const int64_t i = from + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= *n_dense && i <= n_slots) doff[i] = *total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -227,6 +277,175 @@ __global__ __launch_bounds__(256) void k_len_offsets(const uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same offsets in one pass over the lengths: every workgroup takes the next tile (a ticket, so that tiles start in
+// order), adds up its tile, publishes the sum, and finds the sum of all tiles before it by looking back - 64 tiles at a
+// time - for the nearest tile that has already published its inclusive prefix, adding the plain sums of the tiles in
+// between; it then publishes its own inclusive prefix and writes its offsets.  A tile's word carries a two-bit flag (0
+// nothing yet, 1 the tile's sum, 2 the inclusive prefix) above 62 bits of value: written and read whole.
+//
+// SRC 0: lengths from the pairs (+ prefix lengths); SRC 1: lengths as int64 (DELTA_LENGTH_BYTE_ARRAY straight from the
+// decoded length stream: a negative length - make([]byte, n) panics in the reference - or one of 16 MiB or more is noted
+// per page in page_flags, bits 0 and 1; n_dense: on the device, the number of values in front; the slots behind read 0).
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kScanValueMask = (1ull << 62) - 1;
+constexpr int kLbTile = 4096;             // values per tile of the one-pass scan
+constexpr uint32_t kScanSpinLimit = 1u << 24;
+
+struct LenScanArgs {
+  const uint64_t *pairs;     // SRC 0
+  const int64_t *prefix;     // SRC 0: or nullptr
+  const int64_t *lens;       // SRC 1
+  const int64_t *n_dense;    // SRC 1: lens[i] counts for i < *n_dense only
+  int64_t n;                 // slots: doff gets n + 1 entries
+  uint64_t *state;           // one word per tile, zeroed
+  uint32_t *ticket;          // zeroed; [1]: set when a look-back gave up (never, with tiles started in ticket order)
+  int64_t *doff;
+  int64_t *total_out;        // or nullptr: the byte total once more (the handle's block of totals)
+  int32_t *page_flags;       // SRC 1: per data page
+};
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_len_scan(ChunkCtx c, LenScanArgs a) {
+  __shared__ int64_t s_wave[4];
+  __shared__ int64_t s_excl;
+  __shared__ uint32_t s_tile;
+  constexpr int kPerWave = kLbTile / 4, kSteps = kPerWave / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = atomicAdd(a.ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int64_t n = a.n;
+  const int64_t lim = SRC == 1 ? (*a.n_dense < n ? *a.n_dense : n) : n;
+  const int64_t base = (int64_t)tile * kLbTile + wave * kPerWave;
+  int64_t l0[kSteps], l1[kSteps];
+  int bad = 0;
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const int64_t i = base + s * 128 + lane * 2;
+    l0[s] = 0; l1[s] = 0;
+    if (SRC == 0) {
+      if (i + 1 < n) {
+        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(a.pairs + i);
+        l0[s] = (int64_t)(q.x >> 40); l1[s] = (int64_t)(q.y >> 40);
+        if (a.prefix) { const longlong2 r = *reinterpret_cast<const longlong2 *>(a.prefix + i); l0[s] += r.x; l1[s] += r.y; }
+      } else if (i < n) {
+        l0[s] = value_len(a.pairs, a.prefix, i);
+      }
+    } else {
+      if (i + 1 < lim) { const longlong2 r = *reinterpret_cast<const longlong2 *>(a.lens + i); l0[s] = r.x; l1[s] = r.y; }
+      else if (i < lim) l0[s] = a.lens[i];
+      if (l0[s] < 0 || l0[s] > kMaxStrLen) { bad |= l0[s] < 0 ? 1 : 2; bad |= 4; l0[s] = 0; }
+      if (l1[s] < 0 || l1[s] > kMaxStrLen) { bad |= l1[s] < 0 ? 1 : 2; bad |= 8; l1[s] = 0; }
+    }
+  }
+  if (SRC == 1 && bad) {
+    // (rare) the page of the bad length: the last data page whose values start at or before it
+#pragma unroll 1
+    for (int s = 0; s < kSteps; s++) {
+      for (int k = 0; k < 2; k++) {
+        const int64_t i = base + s * 128 + lane * 2 + k;
+        if (i >= lim) continue;
+        const int64_t v = a.lens[i];
+        if (v >= 0 && v <= kMaxStrLen) continue;
+        int lo = 0, hi = c.nd;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (c.state[c.streams[2 * c.nd + mid].page].dense_base <= i) lo = mid; else hi = mid;
+        }
+        atomicOr(&a.page_flags[lo], v < 0 ? 1 : 2);
+      }
+    }
+  }
+  // exclusive offsets inside the wave's quarter
+  int64_t carry = 0, ex[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    int64_t x = l0[s] + l1[s];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    ex[s] = carry + x - (l0[s] + l1[s]);
+    carry += __shfl(x, 63);
+  }
+  if (lane == 0) s_wave[wave] = carry;
+  __syncthreads();
+  if (wave == 0) {
+    const int64_t sum = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (lane == 0) __hip_atomic_store(&a.state[tile], (1ull << 62) | ((uint64_t)sum & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t excl = 0;
+    int64_t at = (int64_t)tile - 1;
+    bool gave_up = false;
+    while (at >= 0) {
+      const int64_t idx = at - lane;
+      uint64_t w = 2ull << 62;                 // in front of tile 0: an inclusive prefix of nothing
+      uint32_t spins = 0;
+      if (idx >= 0) {
+        w = __hip_atomic_load(&a.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((w >> 62) == 0 && ++spins < kScanSpinLimit) {
+          __builtin_amdgcn_s_sleep(1);
+          w = __hip_atomic_load(&a.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (__ballot((w >> 62) == 0) != 0ull) { gave_up = true; break; }
+      const uint64_t pm = __ballot((w >> 62) == 2);
+      const int first_p = pm ? (int)__builtin_ctzll(pm) : 64;       // the nearest tile that knows everything before it
+      int64_t v = lane <= first_p ? (int64_t)(w & kScanValueMask) : 0;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      excl += v;
+      if (pm) break;
+      at -= 64;
+    }
+    if (lane == 0) {
+      if (gave_up) {      // (the call fails rather than hand out offsets that may be wrong)
+        a.ticket[1] = 1u; excl = 0;
+        if (c.nd > 0) set_status_b(&c.state[c.streams[2 * c.nd].page].status, PQD_ERR_HIP);
+      }
+      __hip_atomic_store(&a.state[tile], (2ull << 62) | ((uint64_t)(excl + sum) & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+    }
+  }
+  __syncthreads();
+  int64_t off = s_excl;
+  for (int w = 0; w < wave; w++) off += s_wave[w];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const int64_t i = base + s * 128 + lane * 2;
+    const int64_t o0 = off + ex[s];
+    if (i + 1 <= n) *reinterpret_cast<longlong2 *>(a.doff + i) = longlong2{o0, o0 + l0[s]};     // (index n is the total: the array has n + 1 entries and slack)
+    else if (i <= n) a.doff[i] = o0;
+  }
+  if (a.total_out && (int64_t)tile == n / kLbTile && threadIdx.x == 0) {
+    // the tile that holds index n knows the total: everything before it plus its own values
+    *a.total_out = s_excl + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+}
+
+// DELTA_LENGTH_BYTE_ARRAY pages whose offsets came straight from the decoded lengths (k_len_scan<1>): what k_dlba_pairs
+// checks otherwise - a bad length, strings that run past the page - and where the page's bytes start and end.
+__global__ __launch_bounds__(64) void k_dlba_check(ChunkCtx c, const int64_t *__restrict__ doff, const int32_t *__restrict__ page_flags) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= c.nd) return;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t total = doff[ps->dense_base + ps->cnt] - doff[ps->dense_base];
+  const int f = page_flags[d];
+  if ((f & 2) || ps->aux0 + total > ps->val_off + ps->val_len) set_status_b(&ps->status, PQD_ERR_REFUSED);   // the reference would zero pad a cut string (or hit EOF at the next one)
+  else if (f & 1) set_status_b(&ps->status, PQD_ERR_MALFORMED);
+  ps->aux1 = ps->aux0 + total;  // end of the payload
+}
+
+// lengths of failed pages read as 0 (their words may hold anything, and the chunk-wide offsets are sums over all of them)
+__global__ __launch_bounds__(256) void k_void_failed_lens(ChunkCtx c, int64_t *lens) {
+  const int d = blockIdx.x;
+  const int p = c.streams[2 * c.nd + d].page;
+  const PageState *ps = &c.state[p];
+  if (ps->status == 0 || ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  for (int i = threadIdx.x; i < ps->cnt; i += 256) lens[base + i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Byte copies.  General form: one thread per value (PLAIN, dictionary).  DELTA_LENGTH_BYTE_ARRAY pages are
 // one contiguous block each: flat 128-bit copy.
 // ---------------------------------------------------------------------------------------------
@@ -265,7 +484,7 @@ __global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint6
   const PageState ps = c.state[p];
   if (ps.status != 0 || ps.cnt <= 0) return;
   const int64_t first = ps.dense_base;
-  const uint8_t *src = c.in + (pairs[first] & kSrcMask);
+  const uint8_t *src = c.in + (pairs ? (int64_t)(pairs[first] & kSrcMask) : ps.aux0);
   uint8_t *dst = bytes_out + doff[first];
   const int64_t n = doff[first + ps.cnt] - doff[first];
   for (int64_t b = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; b < n; b += (int64_t)gridDim.y * 256 * 16) {
@@ -695,7 +914,21 @@ hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, in
 
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, encoding, lens, pairs_out);
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_dlba_offsets(const ChunkCtx &c, const int64_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
+                               int64_t *doff, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dlba_page_bases, dim3(1), dim3(1024), 0, stream, c, page_base);
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
+                     (const int64_t *)page_base, doff);
+  // (a page without values writes nothing: the entries from the last value on are filled in whenever slots can lie behind it,
+  //  and index n_slots always)
+  const int64_t from = tail ? 0 : n_slots;
+  hipLaunchKernelGGL(k_fill_offsets_tail, dim3((unsigned)((n_slots - from + 256) / 256)), dim3(256), 0, stream, doff, from, n_slots,
+                     n_dense, (const int64_t *)(page_base + c.nd));
   return hipGetLastError();
 }
 
@@ -760,6 +993,33 @@ hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int6
   if (n_tiles > 0) hipLaunchKernelGGL(k_len_tile_sums, dim3(n_tiles), dim3(256), 0, stream, pairs, prefix, n, partial);
   hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, stream, partial, n_tiles);
   hipLaunchKernelGGL(k_len_offsets, dim3(n_tiles > 0 ? n_tiles : 1), dim3(256), 0, stream, pairs, prefix, n, partial, n_tiles, doff);
+  return hipGetLastError();
+}
+
+// One-pass offsets.  work: (n / kLbTile + 2) * 8 + 64 bytes of device memory (tile words, then the ticket).
+size_t len_scan_work_bytes(int64_t n) { return ((size_t)(n / kLbTile) + 2) * 8 + 64; }
+
+hipError_t launch_len_scan(const ChunkCtx &c, const uint64_t *pairs, const int64_t *prefix, const int64_t *lens, const int64_t *n_dense,
+                           int64_t n, void *work, int64_t *doff, int64_t *total_out, int32_t *page_flags, hipStream_t stream) {
+  const int n_tiles = (int)(n / kLbTile) + 1;        // (the tile that holds index n included)
+  hipError_t e = hipMemsetAsync(work, 0, len_scan_work_bytes(n), stream);
+  if (e != hipSuccess) return e;
+  LenScanArgs a;
+  a.pairs = pairs; a.prefix = prefix; a.lens = lens; a.n_dense = n_dense; a.n = n;
+  a.state = static_cast<uint64_t *>(work);
+  a.ticket = reinterpret_cast<uint32_t *>(a.state + n_tiles + 1);
+  a.doff = doff; a.total_out = total_out; a.page_flags = page_flags;
+  if (lens) {
+    if (c.nd > 0) {
+      e = hipMemsetAsync(page_flags, 0, 4 * (size_t)c.nd, stream);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_void_failed_lens, dim3(c.nd), dim3(256), 0, stream, c, const_cast<int64_t *>(lens));
+    }
+    hipLaunchKernelGGL(k_len_scan<1>, dim3(n_tiles), dim3(256), 0, stream, c, a);
+    if (c.nd > 0) hipLaunchKernelGGL(k_dlba_check, dim3((c.nd + 63) / 64), dim3(64), 0, stream, c, doff, page_flags);
+  } else {
+    hipLaunchKernelGGL(k_len_scan<0>, dim3(n_tiles), dim3(256), 0, stream, c, a);
+  }
   return hipGetLastError();
 }
 

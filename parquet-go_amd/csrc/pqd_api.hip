@@ -136,7 +136,7 @@ struct KernelEvent {
 };
 
 // Process-wide defaults of the per-handle options, read from the environment once (PQD_PRESCAN=wide|wave,
-// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_FUSED=0|1, PQD_HEAVY_LANES=0..4).
+// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_FUSED=0|1, PQD_BYTE_OFFSETS=0|1, PQD_HEAVY_LANES=0..4).
 struct Defaults {
   int opt[PQD_OPT_COUNT];
   int heavy_lanes;
@@ -155,6 +155,7 @@ const Defaults &defaults() {
     if (const char *e = std::getenv("PQD_POISON")) x.opt[PQD_OPT_POISON] = e[0] == '1';
     if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] - '0';
     if (const char *e = std::getenv("PQD_FUSED")) x.opt[PQD_OPT_FUSED] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_BYTE_OFFSETS")) x.opt[PQD_OPT_BYTE_OFFSETS] = e[0] == '1';
     const char *e = std::getenv("PQD_HEAVY_LANES");
     const int v = e ? std::atoi(e) : 0;
     x.heavy_lanes = v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
@@ -200,6 +201,7 @@ struct pqd_handle {
   // output size and done again by pqd_wait when the strings turn out to need more)
   struct BytesPlan {
     bool active = false, any_plain = false, any_dict_enc = false, any_dlba = false, any_dba = false, nullable = false;
+    bool fast_dlba = false;     // DELTA_LENGTH_BYTE_ARRAY pages only, offsets straight from the decoded lengths: no pairs
     int64_t slots = 0;
   } plan;
 
@@ -310,7 +312,7 @@ int launch_byte_copies(pqd_handle *h) {
     Prof pf(h, "k_copy_values");
     HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, d_total, cap, h->stream));
   }
-  if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, bytes_out, d_total, cap, h->stream)); }
+  if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pl.fast_dlba ? nullptr : pairs, doff, bytes_out, d_total, cap, h->stream)); }
   if (pl.any_dba) {
     Prof pf(h, "k_dba_resolve");
     HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), bytes_out, 1,
@@ -546,7 +548,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if ((any_dlba || any_dba) && (rc = h->lens64.ensure(n8))) return rc;
     if (any_dba && (rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
     if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
-    if ((rc = h->scratch.ensure(8 * ((size_t)(slots + 1 + 4095) / 2048 + 8) + 64))) return rc;
+    if (any_dlba && (rc = h->parent.ensure(8 * ((size_t)nd + 2) + 64))) return rc;      // (page bases of a chunk of DELTA_LENGTH_BYTE_ARRAY pages only)
+    if ((rc = h->scratch.ensure(std::max<size_t>(8 * ((size_t)(slots + 1 + 4095) / 2048 + 8) + 64, len_scan_work_bytes(slots) + 64)))) return rc;
+    if ((rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
     // the byte output: every PLAIN / DELTA_LENGTH value lies inside its page, so the page bytes bound it; dictionary
     // and DELTA_BYTE_ARRAY pages may expand beyond that and are then copied again by pqd_wait
     if ((rc = h->bytes.ensure((size_t)all_bytes + 64))) return rc;
@@ -732,7 +736,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     uint64_t *pairs = static_cast<uint64_t *>(h->pairs.p);
     int64_t *lens64 = static_cast<int64_t *>(h->lens64.p);
     int64_t *prefix64 = static_cast<int64_t *>(h->prefix64.p);
-    HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
+    // a chunk of DELTA_LENGTH_BYTE_ARRAY pages only: a string's place in the output follows from the lengths alone, and its
+    // bytes from where its page's length stream ended - no descriptor per value is needed
+    const bool one_pass = h->opt[PQD_OPT_BYTE_OFFSETS] != 0;
+    const bool fast_dlba = one_pass && any_dlba && !any_dba && !any_plain && !any_dict_enc && host_status == PQD_OK;
+    if (!fast_dlba) HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
     // (a dictionary walk that fails part way leaves the remaining entries as they are: they must read as empty
     //  strings, not as whatever the buffer held, because the data pages are still expanded through them)
     if (n_dict) HIP_TRY(hipMemsetAsync(h->dict_pairs.p, 0, 8 * (size_t)std::max<int64_t>(dict_total, 1) + 64, h->stream));
@@ -751,7 +759,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
       { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
-      { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
+      if (!fast_dlba) { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
       HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
@@ -763,12 +771,20 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     // Offsets: a scan over all `slots` descriptors.  The dense values come first; the descriptors behind them are
     // the zeros written above, so the entries from the number of values on all equal the byte total.
     int64_t *doff = static_cast<int64_t *>(nullable ? h->doff.p : h->offsets.p);
-    HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
-    { Prof pf(h, "k_len_offsets");
-      HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, slots, static_cast<int64_t *>(h->scratch.p), doff, h->stream)); }
+    if (fast_dlba) {
+      // page by page, every page starting where the payload sizes of the pages in front put it; should a page hold bytes
+      // behind its last string, pqd_wait computes the offsets again from the lengths alone (dlba_offsets_again)
+      Prof pf(h, "k_dlba_offsets");
+      HIP_TRY(launch_dlba_offsets(c, lens64, static_cast<int64_t *>(h->parent.p), d_totals + 1, slots, nullable, doff, h->stream));
+    } else {
+      HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
+      Prof pf(h, one_pass ? "k_len_scan" : "k_len_offsets");
+      if (one_pass) HIP_TRY(launch_len_scan(c, pairs, any_dba ? prefix64 : nullptr, nullptr, nullptr, slots, h->scratch.p, doff, nullptr, nullptr, h->stream));
+      else HIP_TRY(launch_len_offsets(pairs, any_dba ? prefix64 : nullptr, slots, static_cast<int64_t *>(h->scratch.p), doff, h->stream));
+    }
     HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
     h->plan.active = true; h->plan.any_plain = any_plain; h->plan.any_dict_enc = any_dict_enc; h->plan.any_dlba = any_dlba;
-    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots;
+    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots; h->plan.fast_dlba = fast_dlba;
     if ((rc = launch_byte_copies(h))) return rc;
     if (nullable) {
       const int n_tiles = (int)((slots + 1 + 4095) / 4096);
@@ -860,11 +876,40 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   return PQD_OK;
 }
 
+// A chunk of DELTA_LENGTH_BYTE_ARRAY pages whose offsets were taken from the pages' payload sizes, one of which turned out to
+// hold bytes behind its last string (the reference never looks at them): the offsets once more from the lengths alone, then
+// what depends on them.
+int dlba_offsets_again(pqd_handle *h) {
+  const ChunkCtx &c = h->ctx;
+  const int64_t slots = h->plan.slots;
+  int64_t *d_totals = static_cast<int64_t *>(h->small.p);
+  int64_t *doff = static_cast<int64_t *>(h->plan.nullable ? h->doff.p : h->offsets.p);
+  HIP_TRY(launch_len_scan(c, nullptr, nullptr, static_cast<const int64_t *>(h->lens64.p), d_totals + 1, slots, h->scratch.p, doff, nullptr,
+                          static_cast<int32_t *>(h->dba_flags.p), h->stream));
+  HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
+  int rc;
+  if ((rc = launch_byte_copies(h))) return rc;
+  if (h->plan.nullable) {
+    const int n_tiles = (int)((slots + 1 + 4095) / 4096);
+    HIP_TRY(launch_scatter_rank(static_cast<const int32_t *>(h->def.p), slots, h->col.max_def, static_cast<int64_t *>(h->scratch.p), n_tiles, h->stream));
+    HIP_TRY(launch_scatter_offsets(static_cast<const int32_t *>(h->def.p), slots, h->col.max_def, static_cast<const int64_t *>(h->scratch.p), doff,
+                                   static_cast<int64_t *>(h->offsets.p), h->stream));
+  }
+  HIP_TRY(launch_collect_status(c, c.chunk_status, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
 // Completes the call in flight: totals, status, and for BYTE_ARRAY the byte copies once more when the output was
 // sized too small.
 int finish_call(pqd_handle *h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->no_alloc) HIP_TRY(hipMemcpy(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost));
+  if (h->plan.active && h->plan.fast_dlba && (static_cast<const int32_t *>(h->host_small.p) + kSmallStatus)[kLayoutMismatch] != 0) {
+    int rc = dlba_offsets_again(h);
+    if (rc) return rc;
+  }
   set_busy(h, false);
   const int64_t *tot = static_cast<const int64_t *>(h->host_small.p);
   const int32_t *st = static_cast<const int32_t *>(h->host_small.p) + kSmallStatus;

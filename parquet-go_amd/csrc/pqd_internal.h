@@ -12,6 +12,8 @@ constexpr int kPlainTile = 16384;  // bytes per block-iteration of the flat copy
 // the tile expansion (cleared by k_pages_finalize before); while it is clear the expansion kernels return at once
 constexpr int kWorkFlag = 4;
 constexpr int kDirectCount = 5;    // chunk_status[kDirectCount]: index streams expanded straight from their pages (k_collect_status)
+constexpr int kLayoutMismatch = 6; // chunk_status[kLayoutMismatch]: a DELTA_LENGTH_BYTE_ARRAY page holds bytes behind its last string, so the output
+                                   // offsets taken from the pages' payload sizes are off: the host computes them again from the lengths
 constexpr int kStatusWord = 16;     // chunk_status sits this many 32-bit words into the handle's block of totals
 
 // One page as the host describes it (built from pqd_page_desc).

@@ -80,9 +80,22 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
 // dict_pages == nullptr: the PLAIN data pages; else the listed dictionary pages
 hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint64_t *pairs_out, hipStream_t stream);
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream);
+// A chunk of DELTA_LENGTH_BYTE_ARRAY pages only: offsets straight from the lengths, page by page, each page starting where the
+// payload sizes of the pages in front say (page_base: nd + 1 int64 of work space).  tail: slots may lie behind the last value
+// (nullable column).  chunk_status[kLayoutMismatch] is set when a page holds bytes behind its last string: the offsets behind
+// it are then off and launch_len_scan computes them again.
+hipError_t launch_dlba_offsets(const ChunkCtx &c, const int64_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
+                               int64_t *doff, hipStream_t stream);
 hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream);
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
                               hipStream_t stream);
+// The same offsets in one pass (every tile finds the sum of the tiles before it by looking back).  lens == nullptr: lengths
+// from the pairs (+ prefix).  lens != nullptr: a chunk of DELTA_LENGTH_BYTE_ARRAY pages only, offsets straight from the
+// decoded lengths - no pairs; *n_dense (device) values count, the pages are checked as k_dlba_pairs would (page_flags: one
+// int32 per data page of work space).  total_out (device, may be nullptr) also receives the byte total.
+size_t len_scan_work_bytes(int64_t n);
+hipError_t launch_len_scan(const ChunkCtx &c, const uint64_t *pairs, const int64_t *prefix, const int64_t *lens, const int64_t *n_dense,
+                           int64_t n, void *work, int64_t *doff, int64_t *total_out, int32_t *page_flags, hipStream_t stream);
 // FIXED_LEN_BYTE_ARRAY columns under the two delta byte-array encodings: doff[i] = i * type_length for i in [0, n], and
 // pages holding a string of another length are refused
 hipError_t launch_flba_delta_offsets(const ChunkCtx &c, const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *doff,
@@ -90,6 +103,7 @@ hipError_t launch_flba_delta_offsets(const ChunkCtx &c, const uint64_t *pairs, c
 // The copies write nothing when the byte total (*total, on the device) exceeds cap, the capacity of bytes_out.
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
                               const int64_t *total, int64_t cap, hipStream_t stream);
+// (pairs == nullptr: a page's bytes start where its length stream ended)
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
                                   const int64_t *total, int64_t cap, hipStream_t stream);
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,

@@ -23,7 +23,7 @@ def dec(shared_dec):
     # one handle for the module (its work buffers are reused from test to test, as a reader reuses them from chunk
     # to chunk); kernel-variant choices a test pins are handed back to the library afterwards
     yield shared_dec
-    for opt in range(8):
+    for opt in range(9):
         shared_dec.set_option(opt, -1)
 
 
@@ -1165,7 +1165,9 @@ def test_byte_array_dictionary_page_announcing_more_entries_than_it_holds(dec, o
 
 
 @pytest.mark.parametrize("trim", [False, True])
-def test_delta_length_byte_array(dec, oracle, trim):
+@pytest.mark.parametrize("offsets", [1, 0])
+def test_delta_length_byte_array(dec, oracle, trim, offsets):
+    dec.set_option(8, offsets)               # PQD_OPT_BYTE_OFFSETS
     rng = np.random.default_rng(62)
     cb = pg.ChunkBuilder(gap=1, lead=2)
     cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, 4, oracle.write_delta_length_byte_array([b"Hello", b"World", b"Foobar", b"ABCDEF"]))
@@ -1176,7 +1178,9 @@ def test_delta_length_byte_array(dec, oracle, trim):
 
 
 @pytest.mark.parametrize("trim", [False, True])
-def test_delta_byte_array_prefix_chains(dec, oracle, trim):
+@pytest.mark.parametrize("offsets", [1, 0])
+def test_delta_byte_array_prefix_chains(dec, oracle, trim, offsets):
+    dec.set_option(8, offsets)               # PQD_OPT_BYTE_OFFSETS
     rng = np.random.default_rng(63)
     cb = pg.ChunkBuilder(gap=1)
     cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, 4, oracle.write_delta_byte_array([b"Hello", b"World", b"Foobar", b"ABCDEF"]))
@@ -1193,8 +1197,10 @@ def test_delta_byte_array_prefix_chains(dec, oracle, trim):
     check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
 
 
+@pytest.mark.parametrize("offsets", [1, 0])
 @pytest.mark.parametrize("enc", ["plain", "dict", "dlba", "dba"])
-def test_byte_array_with_nulls(dec, oracle, enc):
+def test_byte_array_with_nulls(dec, oracle, enc, offsets):
+    dec.set_option(8, offsets)               # PQD_OPT_BYTE_OFFSETS
     rng = np.random.default_rng(64)
     cb = pg.ChunkBuilder()
     words = rand_strings(rng, 50, 1, 12)
@@ -1218,7 +1224,9 @@ def test_byte_array_with_nulls(dec, oracle, enc):
     check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY, 0, 2, 1)
 
 
-def test_byte_array_errors(dec, oracle):
+@pytest.mark.parametrize("offsets", [1, 0])
+def test_byte_array_errors(dec, oracle, offsets):
+    dec.set_option(8, offsets)               # PQD_OPT_BYTE_OFFSETS
     # PLAIN value starting exactly at the end -> io.EOF
     cb = pg.ChunkBuilder()
     cb.data_page_v1(pg.ENC_PLAIN, 3, pg.plain_byte_array([b"ab", b"c"]))
@@ -1312,3 +1320,40 @@ def test_flba_delta_string_of_another_length_is_refused(dec, oracle, enc):
     # a column of another physical type still refuses these encodings
     g = dec.decode(chunk, pages, pg.INT64)
     assert g.status == -4 and g.bad_page == 0
+
+
+def test_delta_length_pages_with_bad_lengths_and_short_payloads(dec, oracle):
+    # a chunk of DELTA_LENGTH_BYTE_ARRAY pages only takes its offsets straight from the decoded lengths; what the
+    # per-value path checks must still be found, page by page: a negative length (make([]byte, n) panics in the
+    # reference, encodingread.go:400), a payload shorter than its lengths say (the reference pads: refused), trailing
+    # bytes behind the last string (ignored by the reference), a page of empty strings, each behind good pages
+    rng = np.random.default_rng(6262)
+    good = [rand_strings(rng, n, 0, 50) for n in (3000, 1, 700)]
+
+    def build(bad_body, bad_n):
+        cb = pg.ChunkBuilder(gap=2, lead=1)
+        for strs in good[:2]:
+            cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, len(strs), pg.dlba_encode(strs))
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, bad_n, bad_body)
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, len(good[2]), pg.dlba_encode(good[2]))
+        return cb.finish()
+
+    strs = rand_strings(rng, 500, 1, 30)
+    lens = np.array([len(x) for x in strs], np.int64)
+    payload = b"".join(strs)
+    neg = lens.copy(); neg[250] = -5
+    for body, n, ok in ((pg.delta_encode(lens, np.int64) + payload + b"trailing", 500, True),
+                        (pg.delta_encode(neg, np.int64) + payload, 500, False),
+                        (pg.delta_encode(np.zeros(40, np.int64), np.int64), 40, True)):
+        chunk, pages = build(body, n)
+        for offsets in (1, 0):
+            dec.set_option(8, offsets)
+            g, o = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+            assert (o.status == 0) == ok and (ok or o.bad_page == 2)
+    # a payload shorter than its lengths say: the reference zero pads the cut string (bytes.Reader.Read is lenient), the
+    # library refuses the page, on either path
+    chunk, pages = build(pg.delta_encode(lens, np.int64) + payload[:-7], 500)
+    for offsets in (1, 0):
+        dec.set_option(8, offsets)
+        g = dec.decode(chunk, pages, pg.BYTE_ARRAY)
+        assert g.status == -13 and g.bad_page == 2
