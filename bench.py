@@ -652,6 +652,37 @@ def run_extras(args, dec, local_rank, rank, world, dist, red_dev, cpu_sample, cp
                                        "decoded_GBps": round(n * 4 / best / 1e9, 2), "ms": round(best * 1e3, 2)}
         except Exception as ex:
             extra["host_to_host"] = {"error": repr(ex)}
+
+    # ---- host to host for the other encodings: chunk read into the handle's page-locked input buffer, result read in
+    # place from its page-locked memory (the fastest host route; PCIe both ways) ----
+    if solo and wanted("host_to_host_others"):
+        def e2e(chunk, pages, ptype, md, mr, out_bytes_of):
+            best = None
+            for i in range(3):
+                buf = dec.input_buffer(chunk.size)
+                buf[:] = chunk
+                t1 = time.perf_counter()
+                dec.submit(buf, pages, ptype, 0, md, mr)
+                t = dec.fetch_pinned()
+                dt = time.perf_counter() - t1
+                assert t.status == 0
+                best = dt if best is None else min(best, dt)
+            ob = out_bytes_of(t)
+            return {"decoded_GBps": round(ob / best / 1e9, 2), "ms": round(best * 1e3, 2), "in_bytes": int(chunk.size), "out_bytes": int(ob)}
+        try:
+            res = {}
+            chunk, pages = pqgen.delta_chunk(0x5EED0013, 64 << 20, 12, 128 << 10, 8)
+            res["delta_int64_64Mi"] = e2e(chunk, pages, pq.INT64, 0, 0, lambda t: t.n_slots * 8)
+            chunk, pages = pqgen.strings_chunk(0x5EED0014, 16_000_000, 64 << 10, 0)
+            res["delta_length_byte_array_16M_strings"] = e2e(chunk, pages, pq.BYTE_ARRAY, 0, 0, lambda t: t.offsets.nbytes + t.bytes.nbytes)
+            chunk, pages = pqgen.strings_chunk(0x5EED0014, 16_000_000, 64 << 10, 1)
+            res["delta_byte_array_16M_strings"] = e2e(chunk, pages, pq.BYTE_ARRAY, 0, 0, lambda t: t.offsets.nbytes + t.bytes.nbytes)
+            chunk, pages = pqgen.list_chunk(0x5EED0015, 32 << 20, 128 << 10)
+            res["list_int64_32Mi_slots"] = e2e(chunk, pages, pq.INT64, 3, 1, lambda t: t.n_slots * 16)
+            res["workload"] = "page-locked input buffer of the handle (pqd_input_buffer) -> H2D -> decode -> D2H into the handle's page-locked memory (pqd_result_host)"
+            extra["pinned_to_pinned_others"] = res
+        except Exception as ex:
+            extra["pinned_to_pinned_others"] = {"error": repr(ex)}
     return extra
 
 
