@@ -75,10 +75,11 @@ __global__ void k_plain_ba_walk(ChunkCtx c, const int32_t *__restrict__ dict_pag
 // follow each other in the output as they do in the page, so value i goes to page_base[d] + (its position - the payload's
 // start), page_base being the payload sizes of the pages in front added up (k_dlba_page_bases).  A page that holds bytes
 // behind its last string makes those sums wrong for every page after it: noted in chunk_status[kLayoutMismatch].
-__global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out,
+constexpr int kPairsThreads = 1024;   // (a page is one workgroup's: the more threads, the fewer rounds and barriers)
+__global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out,
                                                     const int64_t *__restrict__ page_base, int64_t *__restrict__ doff) {
   constexpr int kPer = 4;  // consecutive values per thread and round
-  __shared__ int64_t s_wave[4];
+  __shared__ int64_t s_wave[kPairsThreads / 64];
   __shared__ int64_t s_carry;
   __shared__ int s_bad, s_refused;
   const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
   const int64_t out0 = doff ? page_base[d] - pay0 : 0;
   if (tid == 0) { s_carry = ps->aux0; s_bad = 0; s_refused = 0; }
   __syncthreads();
-  for (int64_t i0 = 0; i0 < cnt; i0 += 256 * kPer) {
+  for (int64_t i0 = 0; i0 < cnt; i0 += kPairsThreads * kPer) {
     const int64_t carry = s_carry;
     int64_t ln[kPer], sum = 0;
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
       if (ln[j] > kMaxStrLen) { s_refused = 1; ln[j] = 0; }
       sum += ln[j];
     }
-    // exclusive scan of the threads' sums: shuffles inside the wave, LDS across the four waves
+    // exclusive scan of the threads' sums: shuffles inside the wave, LDS across the waves
     int64_t x = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int64_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_dlba_pairs(ChunkCtx c, int encoding, co
       }
       src += ln[j];
     }
-    if (tid == 255) s_carry = src;   // the last thread ends where the round ends
+    if (tid == kPairsThreads - 1) s_carry = src;   // the last thread ends where the round ends
     __syncthreads();
   }
   if (tid == 0) {
@@ -487,9 +488,17 @@ __global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint6
   const uint8_t *src = c.in + (pairs ? (int64_t)(pairs[first] & kSrcMask) : ps.aux0);
   uint8_t *dst = bytes_out + doff[first];
   const int64_t n = doff[first + ps.cnt] - doff[first];
-  for (int64_t b = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; b < n; b += (int64_t)gridDim.y * 256 * 16) {
-    if (b + 16 <= n) *reinterpret_cast<V16U *>(dst + b) = *reinterpret_cast<const V16U *>(src + b);
-    else for (int k = 0; b + k < n; k++) dst[b + k] = src[b + k];
+  // The stores are aligned (whole lines leave a wavefront), the loads take whatever alignment that leaves them: the first
+  // bytes up to the output's next 16-byte boundary are copied one by one.
+  const int64_t head = n < 16 ? n : (int64_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
+  if (blockIdx.y == 0 && threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+  for (int64_t b = head + ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; b < n; b += (int64_t)gridDim.y * 256 * 16) {
+    if (b + 16 <= n) {
+      const V16U x = *reinterpret_cast<const V16U *>(src + b);
+      *reinterpret_cast<uint4 *>(dst + b) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    } else {
+      for (int k = 0; b + k < n; k++) dst[b + k] = src[b + k];
+    }
   }
 }
 
@@ -914,7 +923,7 @@ hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, in
 
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
   return hipGetLastError();
 }
 
@@ -922,7 +931,7 @@ hipError_t launch_dlba_offsets(const ChunkCtx &c, const int64_t *lens, int64_t *
                                int64_t *doff, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_dlba_page_bases, dim3(1), dim3(1024), 0, stream, c, page_base);
-  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(256), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
                      (const int64_t *)page_base, doff);
   // (a page without values writes nothing: the entries from the last value on are filled in whenever slots can lie behind it,
   //  and index n_slots always)
