@@ -556,6 +556,117 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A chunk of DELTA_BYTE_ARRAY pages only, every string at most kChainMax bytes: no descriptor per value.  Where a string's
+// suffix lies and where the string goes follow from sums of the two decoded length arrays, kept per block of 64 strings:
+// k_dba_sums leaves {suffix bytes, string bytes} of every block (and its smallest prefix length), k_dba_page_scan turns
+// them into offsets inside the page, k_dba_page_bases gives every page its place in the output, and k_dba_chain works
+// out the rest (one wave scan per block) as it walks the strings, writing the offsets on the way.  These kernels decide
+// nothing about the input: anything but clean pages - a length out of range, a prefix longer than the string before it,
+// a string above kChainMax, suffixes running past the page, a page that failed earlier - sets
+// chunk_status[kLayoutMismatch] and the call is decoded again by the kernels that keep a descriptor per value.
+// Block b of a page lies at index dense_base + b of the arrays (a page has fewer blocks than strings).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int64_t *prefix, const int64_t *__restrict__ lens, uint2 *__restrict__ blk,
+                                                  int32_t *__restrict__ bmin) {
+  const int d = blockIdx.x, lane = threadIdx.x & 63;
+  const int p = c.streams[2 * c.nd + d].page;
+  const PageState *ps = &c.state[p];
+  if (ps->status != 0) {     // (its strings read as empty ones: the other kernels know how)
+    if (blockIdx.y == 0 && threadIdx.x == 0) c.chunk_status[kLayoutMismatch] = 1;
+    return;
+  }
+  if (ps->cnt <= 0) return;
+  const int64_t base = ps->dense_base;
+  const int cnt = ps->cnt;
+  const int n_blk = (cnt + 63) >> 6;
+  bool odd = false;
+  for (int b = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6); b < n_blk; b += (int)gridDim.y * 4) {
+    const int i = 64 * b + lane;
+    int64_t P = 0, S = 0;
+    if (i < cnt) { P = i == 0 ? 0 : prefix[base + i]; S = lens[base + i]; }   // (the first prefix length is ignored, encodingread.go:427)
+    if (i == 0) prefix[base] = 0;
+    if (P < 0 || P > kChainMax || S < 0 || S > kChainMax || P + S > kChainMax) { odd = true; P = 0; S = 0; }
+    // a prefix longer than the string before it: a slice out of range in the reference (encodingread.go:430)
+    int64_t before = __shfl_up(P + S, 1);
+    if (lane == 0) before = b == 0 ? 0 : (64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + lens[base + 64 * b - 1];
+    if (i > 0 && i < cnt && P > before) odd = true;
+    const int sum_s = wave_sum_i32((int)S), sum_l = wave_sum_i32((int)(P + S));
+    int mn = i < cnt ? (int)P : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mn, o); mn = y < mn ? y : mn; }
+    if (lane == 0) { blk[base + b] = make_uint2((uint32_t)sum_s, (uint32_t)sum_l); bmin[base + b] = mn; }
+  }
+  if (__any(odd) && lane == 0) c.chunk_status[kLayoutMismatch] = 1;
+}
+
+// The block sums of a page -> where every block's suffixes start (from the page's first suffix byte) and where its strings
+// go (from the page's first output byte); page_tot[d] = the page's output bytes.  One workgroup per page.
+__global__ __launch_bounds__(256) void k_dba_page_scan(ChunkCtx c, uint2 *__restrict__ blk, int64_t *__restrict__ page_tot) {
+  __shared__ uint32_t s_ws[4], s_wl[4];
+  __shared__ uint32_t s_cs, s_cl;
+  __shared__ int s_over;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = c.streams[2 * c.nd + d].page;
+  const PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) { if (tid == 0) page_tot[d] = 0; return; }
+  const int64_t base = ps->dense_base;
+  const int n_blk = (ps->cnt + 63) >> 6;
+  if (tid == 0) { s_cs = 0; s_cl = 0; s_over = 0; }
+  __syncthreads();
+  for (int b0 = 0; b0 < n_blk; b0 += 256) {
+    const uint32_t cs = s_cs, cl = s_cl;
+    const int b = b0 + tid;
+    const uint2 v = b < n_blk ? blk[base + b] : make_uint2(0u, 0u);
+    uint32_t xs = v.x, xl = v.y;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t ys = (uint32_t)__shfl_up((int)xs, o), yl = (uint32_t)__shfl_up((int)xl, o);
+      if (lane >= o) { xs += ys; xl += yl; }
+    }
+    if (lane == 63) { s_ws[wave] = xs; s_wl[wave] = xl; }
+    __syncthreads();   // also: every thread has read the carries
+    uint32_t es = cs + xs - v.x, el = cl + xl - v.y;
+    for (int k = 0; k < wave; k++) { es += s_ws[k]; el += s_wl[k]; }
+    if (b < n_blk) blk[base + b] = make_uint2(es, el);
+    // (a block holds at most 64 KiB, so 32 bits hold the sums of 32 Ki blocks: beyond that the page is left to the other kernels)
+    if (el + v.y < el || es + v.x < es || (el + v.y) > 0x7FFFFFFFu) s_over = 1;
+    if (tid == 255) { s_cs = es + v.x; s_cl = el + v.y; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    page_tot[d] = (int64_t)s_cl;
+    // suffixes that run past the page (the reference would zero pad a cut string, or hit EOF at the next one)
+    if (s_over || ps->aux0 + (int64_t)s_cs > ps->val_off + ps->val_len) c.chunk_status[kLayoutMismatch] = 1;
+  }
+}
+
+// page_tot[d] -> page_base[d] = output bytes of the pages in front, page_base[nd] = their total; one workgroup.
+__global__ __launch_bounds__(1024) void k_dba_page_bases(int nd, const int64_t *__restrict__ page_tot, int64_t *__restrict__ page_base) {
+  __shared__ int64_t s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (nd + 1023) / 1024;
+  const int lo = tid * per, hi = lo + per < nd ? lo + per : nd;
+  int64_t sum = 0;
+  for (int d = lo; d < hi; d++) sum += page_tot[d];
+  int64_t incl = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  int64_t before = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) { if (q < wv) before += s_w[q]; total += s_w[q]; }
+  int64_t run = before + incl - sum;
+  for (int d = lo; d < hi; d++) { const int64_t t = page_tot[d]; page_base[d] = run; run += t; }
+  if (tid == 0) page_base[nd] = total;
+}
+
 // Pages without long strings, strings in order: lane j carries byte j of the previous string; byte j of the next
 // one is that byte when j lies in the shared prefix, else a byte of the suffix.  Suffixes follow each other in the
 // page and so do the outputs, so only the two lengths are per-string inputs.
@@ -571,6 +682,17 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 // one buffer load and one LDS write.  The loads go through a buffer descriptor (offset register plus lane offset,
 // checked against the record count as gfx950 does): one past the end of the chunk returns zero, and no execution
 // mask is needed.  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS instead.
+// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
+__device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return x;
+}
+
 struct DbaBatch {
   int P, L;            // this lane's string: prefix length and whole length
   uint32_t ldoff;      // this lane's string: suffix start minus prefix length, relative to in_base
@@ -589,21 +711,38 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// LEAN: no descriptors and no offsets come in.  `lens` holds the suffix lengths, `blk` the block offsets k_dba_page_scan left,
+// `page_base` the pages' places in the output; a batch is a block of 64 strings of the page (the strings of a block that lie
+// outside the wavefront's range take part in the sums and are passed over by the chain), and the offsets of the strings go
+// out to `doff_out` as the batches are set up - also when the byte output is too small for the bytes themselves, so that
+// everything that depends on the offsets alone is right after the first launch.
+struct DbaLean {
+  const int64_t *lens;
+  const uint2 *blk;
+  const int64_t *page_base;
+  int64_t *doff_out;
+};
+
+template <bool LEAN>
 __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, const int64_t *__restrict__ prefix,
                                                                 const uint64_t *__restrict__ pairs, const int64_t *__restrict__ doff,
                                                                 const int32_t *__restrict__ page_flag, const int32_t *__restrict__ bmin_all,
-                                                                uint8_t *__restrict__ bytes_out, const int64_t *__restrict__ total, int64_t cap) {
+                                                                uint8_t *__restrict__ bytes_out, const int64_t *__restrict__ total, int64_t cap,
+                                                                DbaLean ln) {
   __shared__ uint8_t s_cur_all[kChainWaves][kChainMax + 64];
   __shared__ int s_cut[kChainWaves];
   __shared__ __align__(16) uint8_t s_stage_all[kChainWaves][kStageBytes];
   __shared__ int s_bnd[kChainWaves + 1];
-  if (*total > cap) return;
+  const bool over = *total > cap;     // (uniform)
+  if (over && !LEAN) return;
+  // (LEAN: a chunk that is not clean is decoded again by the other kernels; its lengths may be anything)
+  if (LEAN && c.chunk_status[kLayoutMismatch] != 0) return;
   const int d = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint8_t *s_cur = s_cur_all[wave];
   uint8_t *stage = s_stage_all[wave];
   const int p = c.streams[2 * c.nd + d].page;
-  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || page_flag[d] != 0) return;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_BYTE_ARRAY || (!LEAN && page_flag[d] != 0)) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t base = uniform64(ps->dense_base);
@@ -646,18 +785,56 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
   r_hi = __builtin_amdgcn_readfirstlane(r_hi);
   if (r_lo >= r_hi) return;
 
+  // (LEAN: i0 is a multiple of 64, the batches are the page's blocks one after the other from the range's first on: where a
+  //  block's suffixes and strings start is looked up for the first one and carried along from there)
   struct Fetched { int P, S; uint64_t pr, pr0; int64_t o0; };
+  const int64_t pay0 = LEAN ? uniform64(ps->aux0) : 0;                       // the page's first suffix byte
+  const int64_t out0 = LEAN ? uniform64(ln.page_base[d]) : 0;                // the page's first output byte
   auto fetch_lengths = [&](int i0) {
     Fetched f{0, 0, 0, 0, 0};
     if (i0 < r_hi) {
-      if (i0 + lane < r_hi) { f.P = (int)prefix[base + i0 + lane]; f.pr = pairs[base + i0 + lane]; f.S = (int)(f.pr >> 40); }
-      f.pr0 = (uint64_t)uniform64((int64_t)pairs[base + i0]);
-      f.o0 = uniform64(doff[base + i0]);
+      if (LEAN) {
+        // (k_dba_sums has seen every length inside [0, kChainMax]: the low words are the values, and a pending load holds one register)
+        if (i0 + lane < cnt) {
+          f.P = reinterpret_cast<const int32_t *>(prefix)[2 * (base + i0 + lane)];
+          f.S = reinterpret_cast<const int32_t *>(ln.lens)[2 * (base + i0 + lane)];
+        }
+      } else {
+        if (i0 + lane < r_hi) { f.P = (int)prefix[base + i0 + lane]; f.pr = pairs[base + i0 + lane]; f.S = (int)(f.pr >> 40); }
+        f.pr0 = (uint64_t)uniform64((int64_t)pairs[base + i0]);
+        f.o0 = uniform64(doff[base + i0]);
+      }
     }
     return f;
   };
-  auto make_batch = [&](const Fetched &f) {
+  uint32_t run_s = 0, run_l = 0;     // LEAN: suffix bytes and string bytes of the page in front of the next batch
+  auto make_batch = [&](const Fetched &f, int i0) {
     DbaBatch b;
+    if (LEAN) {
+      // (32-bit sums relative to the page's first suffix byte and first output byte; the scans run on the DPP path, which
+      //  needs no registers besides the value)
+      const uint32_t L = (uint32_t)(f.P + f.S);
+      const uint32_t is = dba_wave_incl_sum((uint32_t)f.S), il = dba_wave_incl_sum(L);
+      const uint32_t srel = run_s + is - (uint32_t)f.S;
+      const uint32_t drel = run_l + il - L;
+      run_s += (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+      run_l += (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
+      const bool live = i0 + lane >= r_lo && i0 + lane < r_hi;
+      if (live) ln.doff_out[base + i0 + lane] = out0 + (int64_t)drel;
+      const int first = i0 < r_lo ? r_lo - i0 : 0;      // the block's first string inside the range
+      const int64_t src0 = pay0 + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)srel, first);
+      // (one opaque scalar: pieces of this sum kept per lane across the loop cost registers the byte loads need)
+      b.out = reinterpret_cast<uint8_t *>(uniform64(reinterpret_cast<int64_t>(bytes_out) + out0 + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)drel, first)));
+      b.in_base = src0 > 64 ? src0 - 64 : 0;
+      b.src = c.in + src0;
+      b.ldoff = live ? srel - (uint32_t)f.P - (uint32_t)(b.in_base - pay0) : 0u;
+      // (a string outside the range keeps the chain's state as it is - every lane below "prefix length 64" - and takes no room)
+      b.P = live ? f.P : 64; b.L = live ? (int)L : 0;
+      int mx = b.L;
+      for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+      b.mx = __builtin_amdgcn_readfirstlane(mx);
+      return b;
+    }
     b.P = f.P; b.L = f.P + f.S;
     int mx = b.L;
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
@@ -699,17 +876,28 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     const int32_t *bmin = bmin_all + base;
     int m = (int)uniform64(prefix[base + r_lo]);     // (<= 64)
     int own_j = 0, own_p = 0;
+    int64_t own_src = 0;      // LEAN: where the owner's suffix starts
     int blk = (r_lo - 1) >> 6;
     while (m > 0) {
       const int j = 64 * blk + lane;
       int pj = 0x7fffffff;
       if (j < r_lo) pj = j == 0 ? 0 : (int)prefix[base + j];
+      int sx = 0;             // LEAN: suffix bytes of the block in front of string j
+      int64_t blk_src = 0;
+      if (LEAN) {
+        const int sj = j < cnt ? (int)ln.lens[base + j] : 0;
+        int x = sj;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        sx = x - sj;
+        blk_src = pay0 + (int64_t)ln.blk[base + blk].x;
+      }
       for (;;) {
         const uint64_t mk = __ballot(pj < m);
         if (!mk) break;
         const int u = 63 - (int)__builtin_clzll(mk);
         const int pu = __builtin_amdgcn_readlane(pj, u);
-        if (lane >= pu && lane < m) { own_j = 64 * blk + u; own_p = pu; }
+        const int su = LEAN ? __builtin_amdgcn_readlane(sx, u) : 0;
+        if (lane >= pu && lane < m) { own_j = 64 * blk + u; own_p = pu; own_src = blk_src + su; }
         m = pu;
         if (lane >= u) pj = 0x7fffffff;            // the strings from u on are behind us
       }
@@ -724,8 +912,7 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
       }
     }
     if (lane < (int)uniform64(prefix[base + r_lo])) {
-      const uint64_t pr = pairs[base + own_j];
-      const int64_t at = (int64_t)(pr & kSrcMask) + (lane - own_p);
+      const int64_t at = (LEAN ? own_src : (int64_t)(pairs[base + own_j] & kSrcMask)) + (lane - own_p);
       cur = at < c.in_len ? c.in[at] : 0u;
     }
   }
@@ -762,15 +949,23 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
 
   // the byte loads run half a batch ahead of the chain, the lengths two batches ahead
   uint32_t ld_a[32], ld_b[32];
-  Fetched f1 = fetch_lengths(r_lo);
-  DbaBatch cb = make_batch(f1);
-  issue_loads(cb, 0, ld_a);
-  f1 = fetch_lengths(r_lo + 64);
-  for (int i0 = r_lo; i0 < r_hi; i0 += 64) {
+  const int i_first = LEAN ? (r_lo & ~63) : r_lo;
+  if (LEAN) {
+    const uint2 bo = ln.blk[base + (i_first >> 6)];
+    run_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)bo.x);
+    run_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)bo.y);
+  }
+  Fetched f1 = fetch_lengths(i_first);
+  DbaBatch cb = make_batch(f1, i_first);
+  if (!over) issue_loads(cb, 0, ld_a);
+  f1 = fetch_lengths(i_first + 64);
+  for (int i0 = i_first; i0 < r_hi; i0 += 64) {
     const int nb = r_hi - i0 < 64 ? r_hi - i0 : 64;
-    const DbaBatch nbatch = make_batch(f1);
+    const DbaBatch nbatch = make_batch(f1, i0 + 64);
     const Fetched f2 = fetch_lengths(i0 + 128);
-    if (cb.mx <= 64) {
+    if (over) {
+      // (LEAN, the byte output being too small: only the offsets, which make_batch has written)
+    } else if (cb.mx <= 64) {
       if (nb > 32) issue_loads(cb, 1, ld_b);
       const uint32_t mid = chain_half(cb, 0, ld_a, 0);
       if (i0 + 64 < r_hi) issue_loads(nbatch, 0, ld_a);
@@ -782,6 +977,7 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
       s_cur[lane] = (uint8_t)cur;
       for (int k = 0; k < nb; k++) {
         const int pk = __builtin_amdgcn_readlane(cb.P, k), len = __builtin_amdgcn_readlane(cb.L, k);
+        if (len == 0) continue;     // (also the strings of the block that lie outside the range)
         for (int j = lane; j < len; j += 64) {
           uint8_t b;
           if (j >= pk) { b = src[j - pk]; s_cur[j] = b; }
@@ -1056,9 +1252,37 @@ hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t
     hipLaunchKernelGGL(k_dba_prepare, dim3(c.nd), dim3(256), 0, stream, c, prefix, pairs, page_flag, parent);
     hipLaunchKernelGGL(k_dba_parents, dim3(c.nd), dim3(1024), 0, stream, c, prefix, parent, page_flag);
   } else {
-    hipLaunchKernelGGL(k_dba_chain, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, parent, bytes_out, total, cap);
+    hipLaunchKernelGGL(k_dba_chain<false>, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, pairs, doff, page_flag, parent, bytes_out, total, cap, DbaLean{});
     hipLaunchKernelGGL(k_dba_resolve, dim3(c.nd, 16), dim3(256), 0, stream, c, prefix, pairs, parent, doff, page_flag, bytes_out, total, cap);
   }
+  return hipGetLastError();
+}
+
+// A chunk of DELTA_BYTE_ARRAY pages only, step 1: block sums, offsets inside the pages, the pages' places, the byte total
+// (doff[n_slots], and every entry from the last value on: slots of a nullable column can lie behind it).
+// blk: 8 bytes per value slot; bmin: 4 bytes per value slot; page_work: (2 nd + 2) * 8 bytes.
+hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int64_t *prefix, const int64_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
+                                   const int64_t *n_dense, int64_t n_slots, bool tail, int64_t *doff, hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  int64_t *page_tot = page_work, *page_base = page_work + c.nd;
+  hipLaunchKernelGGL(k_dba_sums, dim3(c.nd, c.nd > 4096 ? 1 : 16), dim3(256), 0, stream, c, prefix, lens, static_cast<uint2 *>(blk), bmin);
+  hipLaunchKernelGGL(k_dba_page_scan, dim3(c.nd), dim3(256), 0, stream, c, static_cast<uint2 *>(blk), page_tot);
+  hipLaunchKernelGGL(k_dba_page_bases, dim3(1), dim3(1024), 0, stream, c.nd, (const int64_t *)page_tot, page_base);
+  const int64_t from = tail ? 0 : n_slots;
+  hipLaunchKernelGGL(k_fill_offsets_tail, dim3((unsigned)((n_slots - from + 256) / 256)), dim3(256), 0, stream, doff, from, n_slots,
+                     n_dense, (const int64_t *)(page_base + c.nd));
+  return hipGetLastError();
+}
+
+// ... step 2: the strings, and the offsets of all values in front of the last one
+hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int64_t *prefix, const int64_t *lens, const void *blk, const int32_t *bmin,
+                                 const int64_t *page_work, int64_t *doff, uint8_t *bytes_out, const int64_t *total, int64_t cap,
+                                 hipStream_t stream) {
+  if (c.nd <= 0) return hipSuccess;
+  DbaLean ln;
+  ln.lens = lens; ln.blk = static_cast<const uint2 *>(blk); ln.page_base = page_work + c.nd; ln.doff_out = doff;
+  hipLaunchKernelGGL(k_dba_chain<true>, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, (const uint64_t *)nullptr, (const int64_t *)nullptr,
+                     (const int32_t *)nullptr, bmin, bytes_out, total, cap, ln);
   return hipGetLastError();
 }
 

@@ -202,6 +202,7 @@ struct pqd_handle {
   struct BytesPlan {
     bool active = false, any_plain = false, any_dict_enc = false, any_dlba = false, any_dba = false, nullable = false;
     bool fast_dlba = false;     // DELTA_LENGTH_BYTE_ARRAY pages only, offsets straight from the decoded lengths: no pairs
+    bool fast_dba = false;      // DELTA_BYTE_ARRAY pages only: offsets and sources from sums per 64 strings, no pairs
     int64_t slots = 0;
   } plan;
 
@@ -297,6 +298,9 @@ bool is_dict_enc(int e) { return e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_R
 constexpr int kSmallStatus = kStatusWord;  // int32 index: [16] status, [17] bad page, [20] work flag
 constexpr int kSmallByteTotal = 16;    // int64 index: byte total of a BYTE_ARRAY call
 
+// (2 nd + 2) int64 words behind the page flags: output bytes and output base of every page of a chunk of DELTA_BYTE_ARRAY pages only
+int64_t *dba_page_work(pqd_handle *h) { return reinterpret_cast<int64_t *>(static_cast<uint8_t *>(h->dba_flags.p) + align_up(4 * (size_t)h->nd + 64, 256)); }
+
 // The byte copies of a BYTE_ARRAY call, against the current capacity of h->bytes.
 int launch_byte_copies(pqd_handle *h) {
   const pqd_handle::BytesPlan &pl = h->plan;
@@ -313,7 +317,11 @@ int launch_byte_copies(pqd_handle *h) {
     HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, d_total, cap, h->stream));
   }
   if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pl.fast_dlba ? nullptr : pairs, doff, bytes_out, d_total, cap, h->stream)); }
-  if (pl.any_dba) {
+  if (pl.fast_dba) {
+    Prof pf(h, "k_dba_chain");
+    HIP_TRY(launch_dba_lean_chain(c, prefix64, static_cast<const int64_t *>(h->lens64.p), h->pairs.p, static_cast<const int32_t *>(h->parent.p),
+                                  dba_page_work(h), const_cast<int64_t *>(doff), bytes_out, d_total, cap, h->stream));
+  } else if (pl.any_dba) {
     Prof pf(h, "k_dba_resolve");
     HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), bytes_out, 1,
                                d_total, cap, h->stream));
@@ -546,11 +554,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     const size_t n8 = 8 * ((size_t)slots + 2) + 64;
     if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->offsets.ensure(n8))) return rc;
     if ((any_dlba || any_dba) && (rc = h->lens64.ensure(n8))) return rc;
-    if (any_dba && (rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
     if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
     if (any_dlba && (rc = h->parent.ensure(8 * ((size_t)nd + 2) + 64))) return rc;      // (page bases of a chunk of DELTA_LENGTH_BYTE_ARRAY pages only)
     if ((rc = h->scratch.ensure(std::max<size_t>(8 * ((size_t)(slots + 1 + 4095) / 2048 + 8) + 64, len_scan_work_bytes(slots) + 64)))) return rc;
-    if ((rc = h->dba_flags.ensure(4 * (size_t)nd + 64))) return rc;
+    if ((rc = h->dba_flags.ensure(align_up(4 * (size_t)nd + 64, 256) + 8 * (2 * (size_t)nd + 2) + 64))) return rc;
     // the byte output: every PLAIN / DELTA_LENGTH value lies inside its page, so the page bytes bound it; dictionary
     // and DELTA_BYTE_ARRAY pages may expand beyond that and are then copied again by pqd_wait
     if ((rc = h->bytes.ensure((size_t)all_bytes + 64))) return rc;
@@ -740,7 +747,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     // bytes from where its page's length stream ended - no descriptor per value is needed
     const bool one_pass = h->opt[PQD_OPT_BYTE_OFFSETS] != 0;
     const bool fast_dlba = one_pass && any_dlba && !any_dba && !any_plain && !any_dict_enc && host_status == PQD_OK;
-    if (!fast_dlba) HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
+    // ... and a chunk of DELTA_BYTE_ARRAY pages only gets by with sums per 64 strings (dba_general_again when a page is not clean)
+    const bool fast_dba = one_pass && any_dba && !any_dlba && !any_plain && !any_dict_enc && host_status == PQD_OK;
+    if (!fast_dlba && !fast_dba) HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
     // (a dictionary walk that fails part way leaves the remaining entries as they are: they must read as empty
     //  strings, not as whatever the buffer held, because the data pages are still expanded through them)
     if (n_dict) HIP_TRY(hipMemsetAsync(h->dict_pairs.p, 0, 8 * (size_t)std::max<int64_t>(dict_total, 1) + 64, h->stream));
@@ -762,11 +771,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       if (!fast_dlba) { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
-      HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
+      if (!fast_dba) HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
       { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
       { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream)); }
-      { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
-      { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
+      if (!fast_dba) {
+        { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
+        { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
+      }
     }
     // Offsets: a scan over all `slots` descriptors.  The dense values come first; the descriptors behind them are
     // the zeros written above, so the entries from the number of values on all equal the byte total.
@@ -776,6 +787,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       // behind its last string, pqd_wait computes the offsets again from the lengths alone (dlba_offsets_again)
       Prof pf(h, "k_dlba_offsets");
       HIP_TRY(launch_dlba_offsets(c, lens64, static_cast<int64_t *>(h->parent.p), d_totals + 1, slots, nullable, doff, h->stream));
+    } else if (fast_dba) {
+      Prof pf(h, "k_dba_offsets");
+      HIP_TRY(hipMemsetAsync(c.chunk_status + kLayoutMismatch, 0, 4, h->stream));
+      HIP_TRY(launch_dba_lean_offsets(c, prefix64, lens64, pairs, static_cast<int32_t *>(h->parent.p), dba_page_work(h), d_totals + 1, slots, nullable,
+                                      doff, h->stream));
     } else {
       HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
       Prof pf(h, one_pass ? "k_len_scan" : "k_len_offsets");
@@ -784,7 +800,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
     h->plan.active = true; h->plan.any_plain = any_plain; h->plan.any_dict_enc = any_dict_enc; h->plan.any_dlba = any_dlba;
-    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots; h->plan.fast_dlba = fast_dlba;
+    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots; h->plan.fast_dlba = fast_dlba; h->plan.fast_dba = fast_dba;
     if ((rc = launch_byte_copies(h))) return rc;
     if (nullable) {
       const int n_tiles = (int)((slots + 1 + 4095) / 4096);
@@ -901,6 +917,42 @@ int dlba_offsets_again(pqd_handle *h) {
   return PQD_OK;
 }
 
+// A chunk of DELTA_BYTE_ARRAY pages only that turned out not to be clean (a page that failed, a length out of range, a string
+// above the in-order chain's limit, suffixes running past their page): the kernels that keep a descriptor per value decide
+// what every page is, starting from the decoded lengths again.
+int dba_general_again(pqd_handle *h) {
+  const ChunkCtx &c = h->ctx;
+  const int64_t slots = h->plan.slots;
+  int64_t *d_totals = static_cast<int64_t *>(h->small.p);
+  uint64_t *pairs = static_cast<uint64_t *>(h->pairs.p);
+  int64_t *lens64 = static_cast<int64_t *>(h->lens64.p), *prefix64 = static_cast<int64_t *>(h->prefix64.p);
+  int64_t *doff = static_cast<int64_t *>(h->plan.nullable ? h->doff.p : h->offsets.p);
+  void *dtab = h->opt[PQD_OPT_DELTA_BLOCKS] == 0 ? nullptr : h->delta_blocks.p;
+  const bool dspec = h->opt[PQD_OPT_DELTA_BLOCKS] != 2;
+  h->plan.fast_dba = false;
+  HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));
+  HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
+  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream));
+  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream));
+  HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream));
+  HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream));
+  HIP_TRY(launch_void_failed_pages(c, pairs, prefix64, h->stream));
+  HIP_TRY(launch_len_scan(c, pairs, prefix64, nullptr, nullptr, slots, h->scratch.p, doff, nullptr, nullptr, h->stream));
+  HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
+  int rc;
+  if ((rc = launch_byte_copies(h))) return rc;
+  if (h->plan.nullable) {
+    const int n_tiles = (int)((slots + 1 + 4095) / 4096);
+    HIP_TRY(launch_scatter_rank(static_cast<const int32_t *>(h->def.p), slots, h->col.max_def, static_cast<int64_t *>(h->scratch.p), n_tiles, h->stream));
+    HIP_TRY(launch_scatter_offsets(static_cast<const int32_t *>(h->def.p), slots, h->col.max_def, static_cast<const int64_t *>(h->scratch.p), doff,
+                                   static_cast<int64_t *>(h->offsets.p), h->stream));
+  }
+  HIP_TRY(launch_collect_status(c, c.chunk_status, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQD_OK;
+}
+
 // Completes the call in flight: totals, status, and for BYTE_ARRAY the byte copies once more when the output was
 // sized too small.
 int finish_call(pqd_handle *h) {
@@ -908,6 +960,10 @@ int finish_call(pqd_handle *h) {
   if (h->no_alloc) HIP_TRY(hipMemcpy(h->host_small.p, h->small.p, 256, hipMemcpyDeviceToHost));
   if (h->plan.active && h->plan.fast_dlba && (static_cast<const int32_t *>(h->host_small.p) + kSmallStatus)[kLayoutMismatch] != 0) {
     int rc = dlba_offsets_again(h);
+    if (rc) return rc;
+  }
+  if (h->plan.active && h->plan.fast_dba && (static_cast<const int32_t *>(h->host_small.p) + kSmallStatus)[kLayoutMismatch] != 0) {
+    int rc = dba_general_again(h);
     if (rc) return rc;
   }
   set_busy(h, false);

@@ -106,6 +106,14 @@ hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const in
 // (pairs == nullptr: a page's bytes start where its length stream ended)
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
                                   const int64_t *total, int64_t cap, hipStream_t stream);
+// A chunk of DELTA_BYTE_ARRAY pages only: offsets and suffix positions from sums per 64 strings (blk: 8 bytes per value slot,
+// bmin: 4 bytes per value slot, page_work: (2 nd + 2) * 8 bytes); chunk_status[kLayoutMismatch] is set when a page is not
+// clean, and the call is then decoded by the kernels that keep a descriptor per value.
+hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int64_t *prefix, const int64_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
+                                   const int64_t *n_dense, int64_t n_slots, bool tail, int64_t *doff, hipStream_t stream);
+hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int64_t *prefix, const int64_t *lens, const void *blk, const int32_t *bmin,
+                                 const int64_t *page_work, int64_t *doff, uint8_t *bytes_out, const int64_t *total, int64_t cap,
+                                 hipStream_t stream);
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
                               int32_t *page_flag, uint8_t *bytes_out, int phase, const int64_t *total, int64_t cap,
                               hipStream_t stream);
