@@ -492,9 +492,11 @@ struct DeltaSpec {
   uint64_t n_values;
 };
 
+constexpr int kWalkWinVec = 1024 + 2;     // 16-byte vectors of the walk's LDS window (16 KiB and the reach of a header)
+
 // -> the number of blocks, or -1 when the page is left to k_delta_decode
 __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int ushift, int lane,
-                                              int64_t *src_off_out, uint64_t *first_out, int spec_win, DeltaSpec *spec) {
+                                              int64_t *src_off_out, uint64_t *first_out, int spec_win, DeltaSpec *spec, uint4 *s_win) {
   spec->L = 0;
   if (lane == 0) ps->delta_fast = 0;
   const int64_t cnt = ps->cnt;
@@ -504,6 +506,45 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   if (slen <= 0 || slen > 0x7FFFFF00ll) return -1;
   const uint8_t *src = c.in + src_off;
   const uint32_t end = (uint32_t)slen;
+  // last dword that may be read: the one holding the stream's last byte (a call may span several chunk buffers; what
+  // lies between them is not the caller's to give)
+  const uint8_t *in_last = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(src + end - 1u) & ~(uintptr_t)3);
+
+  // A window of the stream in LDS, from the 16-byte boundary at or below position p (never below the chunk buffer, which is
+  // aligned): all its vectors are asked for before the first is waited for - one trip to memory per window.  Vectors that
+  // reach past the stream's last dword are not read: that dword's vector comes in dword by dword, the rest is zero.
+  uint32_t *win32 = reinterpret_cast<uint32_t *>(s_win);
+  uint32_t wpos = 0, mis = 0;
+  auto stage = [&](uint32_t p) {
+    mis = (uint32_t)(reinterpret_cast<uintptr_t>(src + p) & 15u);
+    wpos = p;
+    const uint8_t *wsrc = src + p - mis;
+    constexpr int kPer = (kWalkWinVec + 63) / 64;
+    uint4 v[kPer];
+    __syncthreads();       // (one wavefront: the reads of the window before are done)
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const uint8_t *a = wsrc + 16 * (lane + 64 * k);
+      const bool ok = lane + 64 * k < kWalkWinVec && a + 12 <= in_last;
+      v[k] = *reinterpret_cast<const uint4 *>(ok ? a : c.in);     // (an unconditional load: with branches around the loads each one is waited for)
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const uint8_t *a = wsrc + 16 * (lane + 64 * k);
+      const bool ok = a + 12 <= in_last;
+      if (lane + 64 * k < kWalkWinVec) s_win[lane + 64 * k] = ok ? v[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const uint8_t *tail = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(in_last) & ~(uintptr_t)15);   // the vector of the last dword
+    if (tail >= wsrc && tail < wsrc + 16 * kWalkWinVec && tail + 12 > in_last && lane < 4 && tail + 4 * lane <= in_last)
+      win32[(tail - wsrc) / 4 + lane] = *reinterpret_cast<const uint32_t *>(tail + 4 * lane);
+    __syncthreads();
+  };
+  auto win_byte = [&](uint32_t p) -> uint32_t {      // the byte at stream position p (inside the window)
+    const uint32_t r = p - wpos + mis;
+    return (win32[r >> 2] >> (8u * (r & 3u))) & 0xFFu;
+  };
+  stage(0);
+
   // stream header: four varints, parsed by every lane alike
   uint32_t q = 0;
   uint64_t hdr[4];
@@ -513,7 +554,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     uint32_t shift = 0;
     for (int n = 0; n < 10; n++) {
       if (q >= end) return -1;                   // a header cut short: the general path
-      const uint32_t b = src[q++];
+      const uint32_t b = win_byte(q++);
       if (shift < 64) v |= (uint64_t)(b & 0x7Fu) << shift;
       if ((b & 0x80u) == 0) break;
       shift += 7;
@@ -528,9 +569,6 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   if (pi.encoding != PQD_ENC_DELTA_BINARY_PACKED && n_values != (uint64_t)cnt) return -1;
   const uint32_t n_blocks = (uint32_t)((n_values - 1 + 127) / 128);
   DeltaBlock *tb = table + delta_table_base(pi);
-  // last dword that may be read: the one holding the stream's last byte (a call may span several chunk buffers; what
-  // lies between them is not the caller's to give)
-  const uint8_t *in_last = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(src + end - 1u) & ~(uintptr_t)3);
 
   auto header_at = [&](uint64_t pj, uint32_t x[4]) {     // the 16 bytes at stream position pj (pj + 5 <= end)
     const uint8_t *a0 = src + (uint32_t)pj;
@@ -551,7 +589,14 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   // differ); anything else is walked as before.
   if (spec_win > 0 && n_blocks >= 2u && (uint64_t)q + 5 <= end) {
     uint32_t x[4];
-    header_at(q, x);
+    {     // (the first block header lies in the window)
+      const uint32_t r = q - wpos + mis, al = (r & 3u) * 8u;
+      uint32_t dw[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) dw[i] = win32[(r >> 2) + i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], al);
+    }
     const DeltaHdr h0 = delta_parse_header(x, q, end, 0u, n_values);
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.size);
     const bool fits = h0.good && L != 0u && ((uint64_t)L << ushift) + 96u <= (uint64_t)spec_win;
@@ -587,59 +632,70 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   }
 
 walk:
-  // One round of the chain takes kSub x 64 blocks: every lane asks for the bytes of kSub guessed headers at once (the
-  // round trip to memory is what a round costs), then the sub-steps are confirmed in order; the first block of
-  // another length ends the round.
-  constexpr int kSub = 4;
+  // The chain is followed inside a window of the stream kept in LDS: a step costs a few LDS reads and the parse, not a
+  // round trip to memory, so a stream whose blocks keep changing length (every other block, for lengths of strings) moves
+  // at the pace of the arithmetic.  The window is loaded whenever the chain leaves it.
   uint32_t pos = q, guess = 0;
   uint32_t b0 = 0;
-  int n_sub = 1;                 // guesses per round: kSub while the lengths hold, one after a round that met another length
   while (b0 < n_blocks) {
-    uint32_t dw[kSub][5];
-    bool mine_s[kSub];
-    uint64_t pj_s[kSub];
-#pragma unroll
-    for (int s = 0; s < kSub; s++) {
-      const uint32_t blk = b0 + 64u * (uint32_t)s + (uint32_t)lane;
-      pj_s[s] = (uint64_t)pos + (uint64_t)(64u * (uint32_t)s + (uint32_t)lane) * guess;
-      mine_s[s] = s < n_sub && blk < n_blocks && ((s == 0 && lane == 0) || guess != 0) && pj_s[s] + 5 <= end;
-      if (mine_s[s]) {
-        // 20 bytes at pj (aligned dwords, clamped at the end of the stream: bytes past it are never looked at)
-        const uint8_t *a0 = src + (uint32_t)pj_s[s];
-        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 3u);
-        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(a0 - al);
-        const uint32_t *wl = reinterpret_cast<const uint32_t *>(in_last);
-#pragma unroll
-        for (int i = 0; i < 5; i++) dw[s][i] = *(w0 + i <= wl ? w0 + i : wl);
-      }
-    }
-    bool go_on = true, held = false;
-#pragma unroll
-    for (int s = 0; s < kSub; s++) {
-      if (!go_on || s >= n_sub) break;
+    if ((uint64_t)pos - wpos + mis + 20 > (uint64_t)kWalkWinVec * 16u) stage(pos);     // (the first window is in place already)
+    for (;;) {
       const uint32_t blk = b0 + (uint32_t)lane;
-      const uint64_t pj64 = pj_s[s];
-      const bool mine = mine_s[s];
+      const uint64_t pj64 = (uint64_t)pos + (uint64_t)(uint32_t)lane * guess;
+      const uint64_t rel = pj64 - wpos + mis;                    // offset of the header in the window
+      const bool inwin = rel + 20 <= (uint64_t)kWalkWinVec * 16u;
+      const bool mine = inwin && blk < n_blocks && (lane == 0 || guess != 0) && pj64 + 5 <= end;
       uint32_t size = 0, data_off = 0, widths = 0, dbytes = 0;
       uint64_t md = 0;
       bool good = false;
+      uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
       if (mine) {
-        const uint32_t pj = (uint32_t)pj64;
-        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(src + pj) & 3u);
-        uint32_t x[4];
+        const uint32_t di = (uint32_t)rel >> 2, al = ((uint32_t)rel & 3u) * 8u;
+        uint32_t dw[5], x[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[s][i + 1], dw[s][i], al * 8u);
-        const DeltaHdr h = delta_parse_header(x, pj, end, blk, n_values);
-        size = h.size; data_off = h.data_off; widths = h.widths; dbytes = h.dbytes; md = h.md; good = h.good;
+        for (int i = 0; i < 5; i++) dw[i] = win32[di + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], al);
+        // The common header in a few instructions: a minimum delta of at most three bytes, a full block (all four
+        // miniblocks needed), the block inside the stream.  Anything else is parsed the long way.
+        const uint32_t c0 = x[0] & 0x80u, c1 = x[0] & 0x8000u, c2 = x[0] & 0x800000u;
+        const uint32_t hl = c0 == 0u ? 1u : (c1 == 0u ? 2u : 3u);
+        const uint32_t wb = __builtin_amdgcn_alignbit(x[1], x[0], 8u * hl);          // the four widths
+        const uint32_t sumw = __builtin_amdgcn_sad_u8(wb, 0u, 0u);
+        const bool small_w = ((wb | (wb + 0x3F3F3F3Fu)) & 0x80808080u) == 0u;       // every width <= 64
+        const uint64_t remaining = n_values - 1 - (uint64_t)blk * 128u;
+        if ((c0 == 0u || c1 == 0u || c2 == 0u) && small_w && remaining >= 128u && pj64 + hl + 4u + 4u * sumw <= end) {
+          md = (x[0] & 0x7Fu) | (hl > 1u ? ((x[0] >> 1) & 0x3F80u) : 0u) | (hl > 2u ? ((x[0] >> 2) & 0x1FC000u) : 0u);
+          widths = wb; dbytes = 4u * sumw; data_off = (uint32_t)pj64 + hl + 4u; size = hl + 4u + dbytes; good = true;
+        }
+        x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
       }
       // lane j sits at a true block start when every lane before it is good and as long as the guess
-      const uint64_t okm = __ballot(good && size == guess);
+      uint64_t okm = __ballot(good && size == guess);
+      // The long way for the one lane that needs it: the first lane that does not continue the chain sits at a true start
+      // too, and when the short parse did not take its header (the stream's last block, a long minimum delta, a width
+      // above 64) it is parsed in full.  The lanes behind it sit wherever the guess put them and mostly look at packed
+      // bytes: what they hold is never used, and parsing them in full every step is what made a step slow.
+      {
+        const int nxt = guess == 0u ? 0 : (okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm));
+        if (lane == nxt && mine && !good) {
+          const uint32_t x[4] = {x0, x1, x2, x3};
+          const DeltaHdr h = delta_parse_header(x, (uint32_t)pj64, end, blk, n_values);
+          size = h.size; data_off = h.data_off; widths = h.widths; dbytes = h.dbytes; md = h.md; good = h.good;
+        }
+        okm = __ballot(good && size == guess);
+      }
       const uint64_t goodm = __ballot(good);
+      const uint64_t inm = __ballot(inwin);
       const int n_chain = okm == ~0ull ? 64 : (int)__builtin_ctzll(~okm);   // lanes [0, n_chain) continue the chain at the guessed length
       // the lane after them is at a true start too (its own length may differ)
       int n_true = n_chain < 64 ? n_chain + 1 : 64;
       if (guess == 0) n_true = 1;
       if (b0 + (uint32_t)n_true > n_blocks) n_true = (int)(n_blocks - b0);
+      // ... as far as the window reaches (its lanes are the leading ones: positions grow with the lane)
+      const int n_in = inm == ~0ull ? 64 : (int)__builtin_ctzll(~inm);
+      if (n_true > n_in) n_true = n_in;
+      if (n_true == 0) break;                      // (the next header lies at the window's end: load again from there)
       const uint64_t want = n_true >= 64 ? ~0ull : ((1ull << n_true) - 1);
       if ((goodm & want) != want) return -1;       // a block the fast path does not take
       if (lane < n_true) {
@@ -653,13 +709,11 @@ walk:
       const uint32_t pos_last = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)pj64), last);
       const uint32_t size_last = (uint32_t)__builtin_amdgcn_readlane((int)size, last);
       pos = pos_last + size_last;
-      // the next sub-step was guessed right when all 64 lanes continued the chain (its first lane then sits at pos)
-      held = n_chain == 64 && n_true == 64 && guess != 0 && size_last == guess;
-      go_on = held && b0 + 64u < n_blocks;
       guess = size_last;
       b0 += (uint32_t)n_true;
+      if (b0 >= n_blocks) break;
+      if ((uint64_t)pos - wpos + mis + 20 > (uint64_t)kWalkWinVec * 16u) break;
     }
-    n_sub = held ? kSub : 1;
   }
   if (lane == 0) {
     tb[n_blocks] = DeltaBlock{0u, 0u, hdr[3]};
@@ -674,6 +728,7 @@ walk:
 }
 
 __global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, int src_sel, DeltaWork w) {
+  __shared__ uint4 s_win[kWalkWinVec];
   const int lane = threadIdx.x;
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
@@ -686,7 +741,7 @@ __global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, i
   DeltaSpec spec;
   spec.L = 0;
   const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, w.ushift, lane, &src_off, &first_raw,
-                                                          w.spec ? w.win_bytes : 0, &spec) : -1;
+                                                          w.spec ? w.win_bytes : 0, &spec, s_win) : -1;
   // the page's units: the ones its blocks fill get their records, the rest of its range holds nothing
   const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + ((int64_t)1 << w.ushift) - 1) >> w.ushift);     // (a stream of one value still has its first value to write)
   for (int64_t j = lane; j < range; j += 64) {
