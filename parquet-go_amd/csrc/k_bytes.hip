@@ -570,9 +570,28 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 // chunk_status[kLayoutMismatch] and the call is decoded again by the kernels that keep a descriptor per value.
 // Block b of a page lies at index dense_base + b of the arrays (a page has fewer blocks than strings).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
+__device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return x;
+}
+
+// the smallest value of the 64 lanes, in lane 63
+__device__ __forceinline__ int dba_wave_min63(int x) {
+  const int big = 0x7fffffff;
+  int y;
+  y = __builtin_amdgcn_update_dpp(big, x, 0x111, 0xF, 0xF, false); x = y < x ? y : x;
+  y = __builtin_amdgcn_update_dpp(big, x, 0x112, 0xF, 0xF, false); x = y < x ? y : x;
+  y = __builtin_amdgcn_update_dpp(big, x, 0x114, 0xF, 0xF, false); x = y < x ? y : x;
+  y = __builtin_amdgcn_update_dpp(big, x, 0x118, 0xF, 0xF, false); x = y < x ? y : x;
+  y = __builtin_amdgcn_update_dpp(big, x, 0x142, 0xA, 0xF, false); x = y < x ? y : x;  // row_bcast:15
+  y = __builtin_amdgcn_update_dpp(big, x, 0x143, 0xC, 0xF, false); x = y < x ? y : x;  // row_bcast:31
+  return x;
 }
 
 __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int64_t *prefix, const int64_t *__restrict__ lens, uint2 *__restrict__ blk,
@@ -589,20 +608,34 @@ __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int64_t *prefix, c
   const int cnt = ps->cnt;
   const int n_blk = (cnt + 63) >> 6;
   bool odd = false;
-  for (int b = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6); b < n_blk; b += (int)gridDim.y * 4) {
-    const int i = 64 * b + lane;
-    int64_t P = 0, S = 0;
-    if (i < cnt) { P = i == 0 ? 0 : prefix[base + i]; S = lens[base + i]; }   // (the first prefix length is ignored, encodingread.go:427)
-    if (i == 0) prefix[base] = 0;
-    if (P < 0 || P > kChainMax || S < 0 || S > kChainMax || P + S > kChainMax) { odd = true; P = 0; S = 0; }
-    // a prefix longer than the string before it: a slice out of range in the reference (encodingread.go:430)
-    int64_t before = __shfl_up(P + S, 1);
-    if (lane == 0) before = b == 0 ? 0 : (64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + lens[base + 64 * b - 1];
-    if (i > 0 && i < cnt && P > before) odd = true;
-    const int sum_s = wave_sum_i32((int)S), sum_l = wave_sum_i32((int)(P + S));
-    int mn = i < cnt ? (int)P : 0x7fffffff;
-    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mn, o); mn = y < mn ? y : mn; }
-    if (lane == 0) { blk[base + b] = make_uint2((uint32_t)sum_s, (uint32_t)sum_l); bmin[base + b] = mn; }
+  // (four blocks per step, their loads asked for together: what a wavefront has in flight is what sets the kernel's rate)
+  constexpr int kB = 4;
+  for (int b0 = ((int)blockIdx.y * 4 + ((int)threadIdx.x >> 6)) * kB; b0 < n_blk; b0 += (int)gridDim.y * 4 * kB) {
+    int64_t Pv[kB], Sv[kB], Bv[kB];
+#pragma unroll
+    for (int k = 0; k < kB; k++) {
+      const int b = b0 + k, i = 64 * b + lane;
+      Pv[k] = 0; Sv[k] = 0; Bv[k] = 0;
+      if (i < cnt) { Pv[k] = prefix[base + i]; Sv[k] = lens[base + i]; }
+      // (lane 0: the string in front of the block)
+      if (lane == 0 && b > 0 && b < n_blk) Bv[k] = (64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + lens[base + 64 * b - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kB; k++) {
+      const int b = b0 + k, i = 64 * b + lane;
+      if (b >= n_blk) break;
+      int64_t P = i == 0 ? 0 : Pv[k], S = Sv[k];    // (the first prefix length is ignored, encodingread.go:427)
+      if (i == 0) prefix[base] = 0;
+      if (P < 0 || P > kChainMax || S < 0 || S > kChainMax || P + S > kChainMax) { odd = true; P = 0; S = 0; }
+      // a prefix longer than the string before it: a slice out of range in the reference (encodingread.go:430)
+      const uint32_t L = (uint32_t)(P + S);
+      int64_t before = (int64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xF, 0xF, false);    // wave_shr:1
+      if (lane == 0) before = Bv[k];
+      if (i > 0 && i < cnt && P > before) odd = true;
+      const uint32_t is = dba_wave_incl_sum((uint32_t)S), il = dba_wave_incl_sum(L);
+      const int mn = dba_wave_min63(i < cnt ? (int)P : 0x7fffffff);
+      if (lane == 63) { blk[base + b] = make_uint2(is, il); bmin[base + b] = mn; }
+    }
   }
   if (__any(odd) && lane == 0) c.chunk_status[kLayoutMismatch] = 1;
 }
@@ -685,17 +718,6 @@ __global__ __launch_bounds__(1024) void k_dba_page_bases(int nd, const int64_t *
 // one buffer load and one LDS write.  The loads go through a buffer descriptor (offset register plus lane offset,
 // checked against the record count as gfx950 does): one past the end of the chunk returns zero, and no execution
 // mask is needed.  Batches holding a string of 65 .. kChainMax bytes keep the previous string in LDS instead.
-// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
-__device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
-  return x;
-}
-
 struct DbaBatch {
   int P, L;            // this lane's string: prefix length and whole length
   uint32_t ldoff;      // this lane's string: suffix start minus prefix length, relative to in_base
