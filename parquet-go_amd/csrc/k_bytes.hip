@@ -8,9 +8,6 @@
 // bits 40..63 = length (strings of 16 MiB or more are rejected).  A chunk-wide exclusive scan of the lengths
 // gives the output offsets; the copies follow.
 #include <hip/hip_runtime.h>
-#ifndef PQD_EXP_CHAIN
-#define PQD_EXP_CHAIN 0
-#endif
 #include "pqd_kernels.h"
 
 namespace pqd {
@@ -875,10 +872,6 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
   // outside the suffix load a neighbouring byte that the chain never selects
   auto issue_loads = [&](const DbaBatch &b, int half, uint32_t ld[32]) {
     if (b.mx > 64) return;
-#if PQD_EXP_CHAIN == 1
-    for (int u = 0; u < 32; u++) ld[u] = b.ldoff + u;
-    return;
-#endif
     const int64_t left = c.in_len - b.in_base;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(c.in + b.in_base), 0, left > 0x7fffffff ? 0x7fffffff : (int)left, kRsrcFlags);
@@ -954,9 +947,7 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     for (int u = 0; u < 32; u++) {
       const int pk = __builtin_amdgcn_readlane(b.P, half ? u + 32 : u), len = __builtin_amdgcn_readlane(b.L, half ? u + 32 : u);
       cur = lane < pk ? cur : ld[u];
-#if PQD_EXP_CHAIN != 2
       *wp = (uint8_t)cur;
-#endif
       wp += len;
       total += (uint32_t)len;
     }
@@ -965,9 +956,6 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     const uint32_t n_chunks = (end + 15) >> 4;
     for (uint32_t j = lane; j < n_chunks; j += 64) {
       const uint32_t lo = 16 * j;
-#if PQD_EXP_CHAIN == 3
-      if (lo == 0xFFFFFFF0u)
-#endif
       if (lo >= a && lo + 16 <= end) *reinterpret_cast<uint4 *>(g0 + lo) = *reinterpret_cast<const uint4 *>(stage + lo);
     }
     // first chunk (lanes 0-15) and last chunk (lanes 16-31) when they are partial
