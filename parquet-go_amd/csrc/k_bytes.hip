@@ -76,7 +76,8 @@ __global__ void k_plain_ba_walk(ChunkCtx c, const int32_t *__restrict__ dict_pag
 // start), page_base being the payload sizes of the pages in front added up (k_dlba_page_bases).  A page that holds bytes
 // behind its last string makes those sums wrong for every page after it: noted in chunk_status[kLayoutMismatch].
 constexpr int kPairsThreads = 1024;   // (a page is one workgroup's: the more threads, the fewer rounds and barriers)
-__global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out,
+template <class LT>     // the decoded lengths: 64-bit words, or 32-bit ones (launch_delta_decode, narrow)
+__global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int encoding, const LT *__restrict__ lens, uint64_t *__restrict__ pairs_out,
                                                     const int64_t *__restrict__ page_base, int64_t *__restrict__ doff) {
   constexpr int kPer = 4;  // consecutive values per thread and round
   __shared__ int64_t s_wave[kPairsThreads / 64];
@@ -85,6 +86,9 @@ __global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int en
   const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != encoding) return;
+  // (32-bit lengths that may not be the reference's 64-bit ones - the delta decode has said so - decide nothing: the call is
+  //  decoded again from 64-bit lengths)
+  if (sizeof(LT) == 4 && c.chunk_status[kLayoutMismatch] != 0) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t cnt = ps->cnt, base = ps->dense_base;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int en
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
       const int64_t i = i0 + (int64_t)tid * kPer + j;
-      ln[j] = i < cnt ? lens[base + i] : 0;
+      ln[j] = i < cnt ? (int64_t)lens[base + i] : 0;
       if (ln[j] < 0) { s_bad = 1; ln[j] = 0; }  // make([]byte, huge) panics in the reference
       if (ln[j] > kMaxStrLen) { s_refused = 1; ln[j] = 0; }
       sum += ln[j];
@@ -141,7 +145,6 @@ __global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int en
 __global__ __launch_bounds__(1024) void k_dlba_page_bases(ChunkCtx c, int64_t *page_base) {
   __shared__ int64_t s_w[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) c.chunk_status[kLayoutMismatch] = 0;
   auto payload = [&](int d) -> int64_t {
     const int p = c.streams[2 * c.nd + d].page;
     const PageState &ps = c.state[p];
@@ -479,6 +482,7 @@ __global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint6
                                                          const int64_t *__restrict__ total, int64_t cap) {
   // grid.x = data pages, grid.y = slices of the page
   if (*total > cap) return;
+  if (!pairs && c.chunk_status[kLayoutMismatch] != 0) return;     // (offsets that are about to be computed again)
   const int d = blockIdx.x;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
@@ -591,7 +595,7 @@ __device__ __forceinline__ int dba_wave_min63(int x) {
   return x;
 }
 
-__global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int64_t *prefix, const int64_t *__restrict__ lens, uint2 *__restrict__ blk,
+__global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int32_t *prefix, const int32_t *__restrict__ lens, uint2 *__restrict__ blk,
                                                   int32_t *__restrict__ bmin) {
   const int d = blockIdx.x, lane = threadIdx.x & 63;
   const int p = c.streams[2 * c.nd + d].page;
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int64_t *prefix, c
       Pv[k] = 0; Sv[k] = 0; Bv[k] = 0;
       if (i < cnt) { Pv[k] = prefix[base + i]; Sv[k] = lens[base + i]; }
       // (lane 0: the string in front of the block)
-      if (lane == 0 && b > 0 && b < n_blk) Bv[k] = (64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + lens[base + 64 * b - 1];
+      if (lane == 0 && b > 0 && b < n_blk) Bv[k] = (int64_t)(64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + (int64_t)lens[base + 64 * b - 1];
     }
 #pragma unroll
     for (int k = 0; k < kB; k++) {
@@ -739,7 +743,7 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane
 // out to `doff_out` as the batches are set up - also when the byte output is too small for the bytes themselves, so that
 // everything that depends on the offsets alone is right after the first launch.
 struct DbaLean {
-  const int64_t *lens;
+  const int32_t *lens;       // (and `prefix` points at 32-bit words too)
   const uint2 *blk;
   const int64_t *page_base;
   int64_t *doff_out;
@@ -769,6 +773,7 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t base = uniform64(ps->dense_base);
   const int cnt = __builtin_amdgcn_readfirstlane(ps->cnt);
+  auto PF = [&](int64_t i) -> int64_t { return LEAN ? (int64_t)reinterpret_cast<const int32_t *>(prefix)[i] : prefix[i]; };
 
   // this wave's range [r_lo, r_hi): from the first string with prefix length 0 at or after an even split when there
   // is one close by; otherwise (large pages) from the split itself, the start state then being worked out by looking
@@ -780,16 +785,16 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     const int upto = may_cut ? (from + 256 < cnt ? from + 256 : cnt) : cnt;
     for (int j0 = from; j0 < upto && lo == cnt; j0 += 64) {
       const int j = j0 + lane;
-      const bool zero = j < upto && (j == 0 || prefix[base + j] == 0);
+      const bool zero = j < upto && (j == 0 || PF(base + j) == 0);
       const uint64_t m = __ballot(zero);
       if (m) lo = j0 + (int)__builtin_ctzll(m);
     }
     if (lo == cnt && may_cut && from < cnt) {
-      if (prefix[base + from] <= 64) { lo = from; cut = 1; }
+      if (PF(base + from) <= 64) { lo = from; cut = 1; }
       else {
         for (int j0 = upto; j0 < cnt && lo == cnt; j0 += 64) {
           const int j = j0 + lane;
-          const bool zero = j < cnt && prefix[base + j] == 0;
+          const bool zero = j < cnt && PF(base + j) == 0;
           const uint64_t m = __ballot(zero);
           if (m) lo = j0 + (int)__builtin_ctzll(m);
         }
@@ -816,10 +821,9 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     Fetched f{0, 0, 0, 0, 0};
     if (i0 < r_hi) {
       if (LEAN) {
-        // (k_dba_sums has seen every length inside [0, kChainMax]: the low words are the values, and a pending load holds one register)
         if (i0 + lane < cnt) {
-          f.P = reinterpret_cast<const int32_t *>(prefix)[2 * (base + i0 + lane)];
-          f.S = reinterpret_cast<const int32_t *>(ln.lens)[2 * (base + i0 + lane)];
+          f.P = reinterpret_cast<const int32_t *>(prefix)[base + i0 + lane];
+          f.S = ln.lens[base + i0 + lane];
         }
       } else {
         if (i0 + lane < r_hi) { f.P = (int)prefix[base + i0 + lane]; f.pr = pairs[base + i0 + lane]; f.S = (int)(f.pr >> 40); }
@@ -896,14 +900,14 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
     // length, m); blocks of 64 strings whose smallest prefix length is not below m are skipped by the minima that
     // k_dba_prepare left.  The page's first string has prefix length 0, so m reaches 0.
     const int32_t *bmin = bmin_all + base;
-    int m = (int)uniform64(prefix[base + r_lo]);     // (<= 64)
+    int m = (int)uniform64(PF(base + r_lo));     // (<= 64)
     int own_j = 0, own_p = 0;
     int64_t own_src = 0;      // LEAN: where the owner's suffix starts
     int blk = (r_lo - 1) >> 6;
     while (m > 0) {
       const int j = 64 * blk + lane;
       int pj = 0x7fffffff;
-      if (j < r_lo) pj = j == 0 ? 0 : (int)prefix[base + j];
+      if (j < r_lo) pj = j == 0 ? 0 : (int)PF(base + j);
       int sx = 0;             // LEAN: suffix bytes of the block in front of string j
       int64_t blk_src = 0;
       if (LEAN) {
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(64 * kChainWaves, 4) void k_dba_chain(ChunkCtx c, c
         if (b0 < 0) { blk = 0; break; }              // (block 0 holds the page's first string: never reached)
       }
     }
-    if (lane < (int)uniform64(prefix[base + r_lo])) {
+    if (lane < (int)uniform64(PF(base + r_lo))) {
       const int64_t at = (LEAN ? own_src : (int64_t)(pairs[base + own_j] & kSrcMask)) + (lane - own_p);
       cur = at < c.in_len ? c.in[at] : 0u;
     }
@@ -1141,15 +1145,15 @@ hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, in
 
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
+  hipLaunchKernelGGL(k_dlba_pairs<int64_t>, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
   return hipGetLastError();
 }
 
-hipError_t launch_dlba_offsets(const ChunkCtx &c, const int64_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
+hipError_t launch_dlba_offsets(const ChunkCtx &c, const int32_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
                                int64_t *doff, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_dlba_page_bases, dim3(1), dim3(1024), 0, stream, c, page_base);
-  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
+  hipLaunchKernelGGL(k_dlba_pairs<int32_t>, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
                      (const int64_t *)page_base, doff);
   // (a page without values writes nothing: the entries from the last value on are filled in whenever slots can lie behind it,
   //  and index n_slots always)
@@ -1283,7 +1287,7 @@ hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t
 // A chunk of DELTA_BYTE_ARRAY pages only, step 1: block sums, offsets inside the pages, the pages' places, the byte total
 // (doff[n_slots], and every entry from the last value on: slots of a nullable column can lie behind it).
 // blk: 8 bytes per value slot; bmin: 4 bytes per value slot; page_work: (2 nd + 2) * 8 bytes.
-hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int64_t *prefix, const int64_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
+hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int32_t *prefix, const int32_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
                                    const int64_t *n_dense, int64_t n_slots, bool tail, int64_t *doff, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   int64_t *page_tot = page_work, *page_base = page_work + c.nd;
@@ -1297,13 +1301,13 @@ hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int64_t *prefix, const int
 }
 
 // ... step 2: the strings, and the offsets of all values in front of the last one
-hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int64_t *prefix, const int64_t *lens, const void *blk, const int32_t *bmin,
+hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int32_t *prefix, const int32_t *lens, const void *blk, const int32_t *bmin,
                                  const int64_t *page_work, int64_t *doff, uint8_t *bytes_out, const int64_t *total, int64_t cap,
                                  hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   DbaLean ln;
   ln.lens = lens; ln.blk = static_cast<const uint2 *>(blk); ln.page_base = page_work + c.nd; ln.doff_out = doff;
-  hipLaunchKernelGGL(k_dba_chain<true>, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, prefix, (const uint64_t *)nullptr, (const int64_t *)nullptr,
+  hipLaunchKernelGGL(k_dba_chain<true>, dim3(c.nd), dim3(64 * kChainWaves), 0, stream, c, reinterpret_cast<const int64_t *>(prefix), (const uint64_t *)nullptr, (const int64_t *)nullptr,
                      (const int32_t *)nullptr, bmin, bytes_out, total, cap, ln);
   return hipGetLastError();
 }

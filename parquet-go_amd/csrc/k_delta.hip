@@ -136,7 +136,7 @@ __device__ __forceinline__ uint64_t gextract(const uint8_t *base16, uint32_t q, 
 // encoding: only pages with this value encoding are decoded.  src_sel 0: the stream starts at the page's value
 // section; 1: it starts where the previous delta stream of the page ended (PageState.aux0).
 template <class T>
-__global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, int encoding, int src_sel) {
+__global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, int encoding, int src_sel, int narrow) {
   __shared__ uint4 ring4[2 * kSeg / 16];
   const uint32_t *ring = reinterpret_cast<const uint32_t *>(ring4);
   const int lane = threadIdx.x;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   const int64_t cnt = ps->cnt;
   if (ps->status != 0 || cnt <= 0) return;  // cnt == 0: ReadDataPageValues returns before reading
   if (ps->delta_fast == 1) return;          // decoded block-parallel
+  if (narrow && lane == 0) c.chunk_status[kLayoutMismatch] = 1;     // (a page the block-parallel kernels left: nothing has checked its blocks)
 
   const int64_t src_off = src_sel ? ps->aux0 : ps->val_off;
   const uint8_t *abs0 = c.in + src_off;
@@ -424,7 +425,18 @@ struct DeltaWork {
   int32_t ushift;       // a unit is 2^ushift blocks (3 .. 6), chosen per call from the bytes the pages spend per value
   int32_t win_bytes;    // LDS window over the packed bytes of a unit (the launch's dynamic LDS)
   int32_t spec;         // pages whose blocks all have one length skip the walk (0: every page is walked)
+  int32_t narrow;       // the values are lengths of strings, kept as 32-bit words (see delta_narrow_ok)
 };
+
+// Lengths of strings are decoded with 32-bit arithmetic and kept as 32-bit words where that is provably the same thing: when
+// the first value and every step from one value to the next are below 2^31 in magnitude (a minimum delta below 2^30, packed
+// deltas of at most 30 bits) and all the 32-bit results lie in the range of a string's length - which their consumers
+// check value by value -, the 64-bit results the reference computes are those very numbers.  A block that does not keep to
+// that sets chunk_status[kLayoutMismatch], and so does a page left to k_delta_decode: the call is then decoded again with
+// 64-bit words by the kernels that decide what such a page is.
+__device__ __forceinline__ bool delta_narrow_ok(uint64_t md_zigzag, uint32_t widths) {
+  return md_zigzag < (1ull << 31) && ((widths | (widths + 0x61616161u)) & 0x80808080u) == 0u;      // every width <= 30
+}
 
 // A unit is 2^ushift blocks, as many as fit the LDS window (at most 64: one block per lane).  What a unit costs beyond
 // its values - its record, its table entries, the wait for its bytes, the totals of the units before it - is the same
@@ -496,7 +508,7 @@ constexpr int kWalkWinVec = 1024 + 2;     // 16-byte vectors of the walk's LDS w
 
 // -> the number of blocks, or -1 when the page is left to k_delta_decode
 __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &pi, PageState *ps, int src_sel, DeltaBlock *table, DeltaUnit *pu, int ushift, int lane,
-                                              int64_t *src_off_out, uint64_t *first_out, int spec_win, DeltaSpec *spec, uint4 *s_win) {
+                                              int64_t *src_off_out, uint64_t *first_out, int spec_win, DeltaSpec *spec, uint4 *s_win, bool narrow) {
   spec->L = 0;
   if (lane == 0) ps->delta_fast = 0;
   const int64_t cnt = ps->cnt;
@@ -563,6 +575,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     hdr[i] = v;
   }
   if (hdr[0] != 128 || hdr[1] != 4) return -1;
+  if (narrow && hdr[3] >= (1ull << 31) && lane == 0) c.chunk_status[kLayoutMismatch] = 1;
   const uint64_t n_values = hdr[2];
   const int64_t nv_page = pi.num_values > 0 ? pi.num_values : 0;
   if (n_values < (uint64_t)cnt || n_values > (uint64_t)nv_page) return -1;       // (short: an error; long: no room in the table)
@@ -699,6 +712,7 @@ walk:
       const uint64_t want = n_true >= 64 ? ~0ull : ((1ull << n_true) - 1);
       if ((goodm & want) != want) return -1;       // a block the fast path does not take
       if (lane < n_true) {
+        if (narrow && !delta_narrow_ok(md, widths)) c.chunk_status[kLayoutMismatch] = 1;
         tb[blk] = DeltaBlock{data_off, widths, md};
         // the byte range of the unit the block belongs to
         const uint32_t ublocks = 1u << ushift;
@@ -741,7 +755,7 @@ __global__ __launch_bounds__(64) void k_delta_blocks(ChunkCtx c, int encoding, i
   DeltaSpec spec;
   spec.L = 0;
   const int64_t nb = pi.encoding == encoding ? delta_walk(c, pi, &c.state[p], src_sel, w.blocks, w.units + ub, w.ushift, lane, &src_off, &first_raw,
-                                                          w.spec ? w.win_bytes : 0, &spec, s_win) : -1;
+                                                          w.spec ? w.win_bytes : 0, &spec, s_win, w.narrow != 0) : -1;
   // the page's units: the ones its blocks fill get their records, the rest of its range holds nothing
   const int64_t ng = nb < 0 ? 0 : (nb == 0 ? 1 : (nb + ((int64_t)1 << w.ushift) - 1) >> w.ushift);     // (a stream of one value still has its first value to write)
   for (int64_t j = lane; j < range; j += 64) {
@@ -922,6 +936,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
                              __builtin_amdgcn_alignbit(d4, d3, sh)};
       const DeltaHdr h = delta_parse_header(x, pj, slen, b0 + (uint32_t)lane, n_values);
       ok = h.good && (h.size == spec_len || b0 + (uint32_t)lane + 1u == n_blocks);
+      if (w.narrow && ok && !delta_narrow_ok(h.md, h.widths)) c.chunk_status[kLayoutMismatch] = 1;
       E = DeltaBlock{h.data_off, h.widths, h.md};
     }
     if (__ballot(!ok) != 0ull) {
@@ -1162,8 +1177,9 @@ size_t delta_work_bytes(int64_t slots, int nd) {
 }
 
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               double bytes_per_value, bool spec, hipStream_t stream) {
+                               double bytes_per_value, bool spec, bool narrow, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
+  if (narrow && (!work || elem_size != 4)) return hipErrorInvalidValue;
   if (work) {
     // Units as large as the window allows, the window as small as the units need: from the bytes the pages spend per
     // value (0: not known - the lengths of byte arrays, which share their pages with the bytes: 32 blocks, 6.5 KiB).
@@ -1185,6 +1201,7 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     w.ushift = ushift;
     w.win_bytes = win_bytes;
     w.spec = spec ? 1 : 0;
+    w.narrow = narrow ? 1 : 0;
     hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
     const dim3 grid((unsigned)w.n_units);
     const size_t shmem = (size_t)win_bytes + kWinSlack;
@@ -1192,9 +1209,9 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     else hipLaunchKernelGGL(k_delta_units<uint64_t>, grid, dim3(64), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
   }
   if (elem_size == 4)
-    hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel);
+    hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel, narrow ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_delta_decode<uint64_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out), encoding, src_sel);
+    hipLaunchKernelGGL(k_delta_decode<uint64_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint64_t *>(values_out), encoding, src_sel, 0);
   return hipGetLastError();
 }
 

@@ -319,7 +319,7 @@ int launch_byte_copies(pqd_handle *h) {
   if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pl.fast_dlba ? nullptr : pairs, doff, bytes_out, d_total, cap, h->stream)); }
   if (pl.fast_dba) {
     Prof pf(h, "k_dba_chain");
-    HIP_TRY(launch_dba_lean_chain(c, prefix64, static_cast<const int64_t *>(h->lens64.p), h->pairs.p, static_cast<const int32_t *>(h->parent.p),
+    HIP_TRY(launch_dba_lean_chain(c, reinterpret_cast<const int32_t *>(prefix64), static_cast<const int32_t *>(h->lens64.p), h->pairs.p, static_cast<const int32_t *>(h->parent.p),
                                   dba_page_work(h), const_cast<int64_t *>(doff), bytes_out, d_total, cap, h->stream));
   } else if (pl.any_dba) {
     Prof pf(h, "k_dba_resolve");
@@ -746,9 +746,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     // a chunk of DELTA_LENGTH_BYTE_ARRAY pages only: a string's place in the output follows from the lengths alone, and its
     // bytes from where its page's length stream ended - no descriptor per value is needed
     const bool one_pass = h->opt[PQD_OPT_BYTE_OFFSETS] != 0;
-    const bool fast_dlba = one_pass && any_dlba && !any_dba && !any_plain && !any_dict_enc && host_status == PQD_OK;
+    const bool fast_dlba = one_pass && dtab && any_dlba && !any_dba && !any_plain && !any_dict_enc && host_status == PQD_OK;
     // ... and a chunk of DELTA_BYTE_ARRAY pages only gets by with sums per 64 strings (dba_general_again when a page is not clean)
-    const bool fast_dba = one_pass && any_dba && !any_dlba && !any_plain && !any_dict_enc && host_status == PQD_OK;
+    const bool fast_dba = one_pass && dtab && any_dba && !any_dlba && !any_plain && !any_dict_enc && host_status == PQD_OK;
+    // (both decode their lengths as 32-bit words: what those paths read and write per value is halved)
+    if (fast_dlba || fast_dba) HIP_TRY(hipMemsetAsync(c.chunk_status + kLayoutMismatch, 0, 4, h->stream));
     if (!fast_dlba && !fast_dba) HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));  // failed pages and the slots beyond the values read as empty strings
     // (a dictionary walk that fails part way leaves the remaining entries as they are: they must read as empty
     //  strings, not as whatever the buffer held, because the data pages are still expanded through them)
@@ -767,13 +769,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     if (any_plain) { Prof pf(h, "k_plain_ba_walk"); HIP_TRY(launch_plain_ba_walk(c, nullptr, 0, pairs, h->stream)); }
     if (any_dlba) {
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), fast_dlba ? 4 : 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, fast_dlba, h->stream)); }
       if (!fast_dlba) { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
     }
     if (any_dba) {
       if (!fast_dba) HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
-      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream)); }
+      { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), fast_dba ? 4 : 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, fast_dba, h->stream)); }
+      { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), fast_dba ? 4 : 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, fast_dba, h->stream)); }
       if (!fast_dba) {
         { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
         { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
@@ -786,11 +788,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       // page by page, every page starting where the payload sizes of the pages in front put it; should a page hold bytes
       // behind its last string, pqd_wait computes the offsets again from the lengths alone (dlba_offsets_again)
       Prof pf(h, "k_dlba_offsets");
-      HIP_TRY(launch_dlba_offsets(c, lens64, static_cast<int64_t *>(h->parent.p), d_totals + 1, slots, nullable, doff, h->stream));
+      HIP_TRY(launch_dlba_offsets(c, reinterpret_cast<const int32_t *>(lens64), static_cast<int64_t *>(h->parent.p), d_totals + 1, slots, nullable, doff, h->stream));
     } else if (fast_dba) {
       Prof pf(h, "k_dba_offsets");
-      HIP_TRY(hipMemsetAsync(c.chunk_status + kLayoutMismatch, 0, 4, h->stream));
-      HIP_TRY(launch_dba_lean_offsets(c, prefix64, lens64, pairs, static_cast<int32_t *>(h->parent.p), dba_page_work(h), d_totals + 1, slots, nullable,
+      HIP_TRY(launch_dba_lean_offsets(c, reinterpret_cast<int32_t *>(prefix64), reinterpret_cast<const int32_t *>(lens64), pairs, static_cast<int32_t *>(h->parent.p), dba_page_work(h), d_totals + 1, slots, nullable,
                                       doff, h->stream));
     } else {
       HIP_TRY(launch_void_failed_pages(c, pairs, any_dba ? prefix64 : nullptr, h->stream));
@@ -835,7 +836,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         if (pi.data_idx >= 0 && pi.encoding == PQD_ENC_DELTA_BINARY_PACKED && pi.num_values > 0) { db += pi.body_len; dv += pi.num_values; }
       }
       Prof pf(h, "k_delta_decode");
-      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, dspec, h->stream));
+      HIP_TRY(launch_delta_decode(c, dense_out, esz, PQD_ENC_DELTA_BINARY_PACKED, 0, dtab, slots, dv > 0 ? (double)db / (double)dv : 0.0, dspec, false, h->stream));
     }
     if (any_dlba || any_dba) {
       // FIXED_LEN_BYTE_ARRAY under DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: the kernels of the BYTE_ARRAY path, their
@@ -846,13 +847,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       int64_t *doff = static_cast<int64_t *>(h->doff.p);
       HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));
       if (any_dlba) {
-        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, false, h->stream)); }
         { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens64, pairs, h->stream)); }
       }
       if (any_dba) {
         HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-        { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream)); }
-        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream)); }
+        { Prof pf(h, "k_delta_decode(prefix)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, false, h->stream)); }
+        { Prof pf(h, "k_delta_decode(lengths)"); HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, false, h->stream)); }
         { Prof pf(h, "k_dlba_pairs"); HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream)); }
         { Prof pf(h, "k_dba_parents"); HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream)); }
       }
@@ -900,6 +901,12 @@ int dlba_offsets_again(pqd_handle *h) {
   const int64_t slots = h->plan.slots;
   int64_t *d_totals = static_cast<int64_t *>(h->small.p);
   int64_t *doff = static_cast<int64_t *>(h->plan.nullable ? h->doff.p : h->offsets.p);
+  // (the lengths were kept as 32-bit words: once more as the 64-bit words the kernels below read - and should the flag have
+  //  been raised by a block that does not fit 32-bit arithmetic, these are the values the reference computes)
+  void *dtab = h->opt[PQD_OPT_DELTA_BLOCKS] == 0 ? nullptr : h->delta_blocks.p;
+  HIP_TRY(hipMemsetAsync(c.chunk_status + kLayoutMismatch, 0, 4, h->stream));      // (the copies below look at it)
+  HIP_TRY(launch_delta_decode(c, static_cast<uint8_t *>(h->lens64.p), 8, PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, 0, dtab, slots, 0.0,
+                              h->opt[PQD_OPT_DELTA_BLOCKS] != 2, false, h->stream));
   HIP_TRY(launch_len_scan(c, nullptr, nullptr, static_cast<const int64_t *>(h->lens64.p), d_totals + 1, slots, h->scratch.p, doff, nullptr,
                           static_cast<int32_t *>(h->dba_flags.p), h->stream));
   HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
@@ -930,10 +937,11 @@ int dba_general_again(pqd_handle *h) {
   void *dtab = h->opt[PQD_OPT_DELTA_BLOCKS] == 0 ? nullptr : h->delta_blocks.p;
   const bool dspec = h->opt[PQD_OPT_DELTA_BLOCKS] != 2;
   h->plan.fast_dba = false;
+  HIP_TRY(hipMemsetAsync(c.chunk_status + kLayoutMismatch, 0, 4, h->stream));
   HIP_TRY(hipMemsetAsync(pairs, 0, 8 * ((size_t)slots + 2), h->stream));
   HIP_TRY(hipMemsetAsync(prefix64, 0, 8 * ((size_t)slots + 2), h->stream));
-  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, h->stream));
-  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, h->stream));
+  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(prefix64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 0, dtab, slots, 0.0, dspec, false, h->stream));
+  HIP_TRY(launch_delta_decode(c, reinterpret_cast<uint8_t *>(lens64), 8, PQD_ENC_DELTA_BYTE_ARRAY, 1, dtab, slots, 0.0, dspec, false, h->stream));
   HIP_TRY(launch_dlba_pairs(c, PQD_ENC_DELTA_BYTE_ARRAY, lens64, pairs, h->stream));
   HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), nullptr, static_cast<int32_t *>(h->dba_flags.p), nullptr, 0, nullptr, 0, h->stream));
   HIP_TRY(launch_void_failed_pages(c, pairs, prefix64, h->stream));

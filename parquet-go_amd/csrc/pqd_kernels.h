@@ -73,8 +73,10 @@ hipError_t launch_scatter_plain_bits(const ChunkCtx &c, const int32_t *tile_pref
 size_t delta_work_bytes(int64_t slots, int nd);
 // bytes_per_value: what the pages of this encoding spend per value (sets how many blocks a wavefront takes at once); 0: not known
 // spec: pages whose blocks all look one length long skip the walk of their block headers (the units check the guess)
+// narrow (elem_size 4, work given): the values are lengths of strings, computed and kept as 32-bit words; whatever could make
+// that differ from the 64-bit values the reference computes sets chunk_status[kLayoutMismatch]
 hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_size, int encoding, int src_sel, void *work, int64_t slots,
-                               double bytes_per_value, bool spec, hipStream_t stream);
+                               double bytes_per_value, bool spec, bool narrow, hipStream_t stream);
 
 // ---- k_bytes.hip ----
 // dict_pages == nullptr: the PLAIN data pages; else the listed dictionary pages
@@ -84,7 +86,7 @@ hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *len
 // payload sizes of the pages in front say (page_base: nd + 1 int64 of work space).  tail: slots may lie behind the last value
 // (nullable column).  chunk_status[kLayoutMismatch] is set when a page holds bytes behind its last string: the offsets behind
 // it are then off and launch_len_scan computes them again.
-hipError_t launch_dlba_offsets(const ChunkCtx &c, const int64_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
+hipError_t launch_dlba_offsets(const ChunkCtx &c, const int32_t *lens, int64_t *page_base, const int64_t *n_dense, int64_t n_slots, bool tail,
                                int64_t *doff, hipStream_t stream);
 hipError_t launch_void_failed_pages(const ChunkCtx &c, uint64_t *pairs, int64_t *prefix, hipStream_t stream);
 hipError_t launch_len_offsets(const uint64_t *pairs, const int64_t *prefix, int64_t n, int64_t *partial, int64_t *doff,
@@ -109,9 +111,9 @@ hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, cons
 // A chunk of DELTA_BYTE_ARRAY pages only: offsets and suffix positions from sums per 64 strings (blk: 8 bytes per value slot,
 // bmin: 4 bytes per value slot, page_work: (2 nd + 2) * 8 bytes); chunk_status[kLayoutMismatch] is set when a page is not
 // clean, and the call is then decoded by the kernels that keep a descriptor per value.
-hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int64_t *prefix, const int64_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
+hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int32_t *prefix, const int32_t *lens, void *blk, int32_t *bmin, int64_t *page_work,
                                    const int64_t *n_dense, int64_t n_slots, bool tail, int64_t *doff, hipStream_t stream);
-hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int64_t *prefix, const int64_t *lens, const void *blk, const int32_t *bmin,
+hipError_t launch_dba_lean_chain(const ChunkCtx &c, const int32_t *prefix, const int32_t *lens, const void *blk, const int32_t *bmin,
                                  const int64_t *page_work, int64_t *doff, uint8_t *bytes_out, const int64_t *total, int64_t cap,
                                  hipStream_t stream);
 hipError_t launch_dba_resolve(const ChunkCtx &c, int64_t *prefix, const uint64_t *pairs, int32_t *parent, const int64_t *doff,
