@@ -582,19 +582,8 @@ __device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
   return x;
 }
 
-// the smallest value of the 64 lanes, in lane 63
-__device__ __forceinline__ int dba_wave_min63(int x) {
-  const int big = 0x7fffffff;
-  int y;
-  y = __builtin_amdgcn_update_dpp(big, x, 0x111, 0xF, 0xF, false); x = y < x ? y : x;
-  y = __builtin_amdgcn_update_dpp(big, x, 0x112, 0xF, 0xF, false); x = y < x ? y : x;
-  y = __builtin_amdgcn_update_dpp(big, x, 0x114, 0xF, 0xF, false); x = y < x ? y : x;
-  y = __builtin_amdgcn_update_dpp(big, x, 0x118, 0xF, 0xF, false); x = y < x ? y : x;
-  y = __builtin_amdgcn_update_dpp(big, x, 0x142, 0xA, 0xF, false); x = y < x ? y : x;  // row_bcast:15
-  y = __builtin_amdgcn_update_dpp(big, x, 0x143, 0xC, 0xF, false); x = y < x ? y : x;  // row_bcast:31
-  return x;
-}
-
+// (a thread takes four consecutive strings, so a block of 64 is one row of 16 lanes and its sums are row reductions: four
+//  blocks per wavefront step, a dozen instructions per block)
 __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int32_t *prefix, const int32_t *__restrict__ lens, uint2 *__restrict__ blk,
                                                   int32_t *__restrict__ bmin) {
   const int d = blockIdx.x, lane = threadIdx.x & 63;
@@ -607,36 +596,49 @@ __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int32_t *prefix, c
   if (ps->cnt <= 0) return;
   const int64_t base = ps->dense_base;
   const int cnt = ps->cnt;
-  const int n_blk = (cnt + 63) >> 6;
+  struct I4 { int32_t v[4]; } __attribute__((packed));
   bool odd = false;
-  // (four blocks per step, their loads asked for together: what a wavefront has in flight is what sets the kernel's rate)
-  constexpr int kB = 4;
-  for (int b0 = ((int)blockIdx.y * 4 + ((int)threadIdx.x >> 6)) * kB; b0 < n_blk; b0 += (int)gridDim.y * 4 * kB) {
-    int64_t Pv[kB], Sv[kB], Bv[kB];
+  for (int g = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6); 256 * g < cnt; g += (int)gridDim.y * 4) {
+    const int i0 = 256 * g + 4 * lane;
+    int P[4] = {0, 0, 0, 0}, S[4] = {0, 0, 0, 0};
+    if (i0 + 3 < cnt) {
+      const I4 pv = *reinterpret_cast<const I4 *>(prefix + base + i0), sv = *reinterpret_cast<const I4 *>(lens + base + i0);
 #pragma unroll
-    for (int k = 0; k < kB; k++) {
-      const int b = b0 + k, i = 64 * b + lane;
-      Pv[k] = 0; Sv[k] = 0; Bv[k] = 0;
-      if (i < cnt) { Pv[k] = prefix[base + i]; Sv[k] = lens[base + i]; }
-      // (lane 0: the string in front of the block)
-      if (lane == 0 && b > 0 && b < n_blk) Bv[k] = (int64_t)(64 * b - 1 == 0 ? 0 : prefix[base + 64 * b - 1]) + (int64_t)lens[base + 64 * b - 1];
-    }
+      for (int k = 0; k < 4; k++) { P[k] = pv.v[k]; S[k] = sv.v[k]; }
+    } else {
 #pragma unroll
-    for (int k = 0; k < kB; k++) {
-      const int b = b0 + k, i = 64 * b + lane;
-      if (b >= n_blk) break;
-      int64_t P = i == 0 ? 0 : Pv[k], S = Sv[k];    // (the first prefix length is ignored, encodingread.go:427)
-      if (i == 0) prefix[base] = 0;
-      if (P < 0 || P > kChainMax || S < 0 || S > kChainMax || P + S > kChainMax) { odd = true; P = 0; S = 0; }
-      // a prefix longer than the string before it: a slice out of range in the reference (encodingread.go:430)
-      const uint32_t L = (uint32_t)(P + S);
-      int64_t before = (int64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xF, 0xF, false);    // wave_shr:1
-      if (lane == 0) before = Bv[k];
-      if (i > 0 && i < cnt && P > before) odd = true;
-      const uint32_t is = dba_wave_incl_sum((uint32_t)S), il = dba_wave_incl_sum(L);
-      const int mn = dba_wave_min63(i < cnt ? (int)P : 0x7fffffff);
-      if (lane == 63) { blk[base + b] = make_uint2(is, il); bmin[base + b] = mn; }
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < cnt) { P[k] = prefix[base + i0 + k]; S[k] = lens[base + i0 + k]; }
     }
+    // (lane 0: the length of the string in front of the group)
+    int before0 = 0;
+    if (lane == 0 && g > 0) before0 = prefix[base + i0 - 1] + lens[base + i0 - 1];     // (i0 - 1 >= 255: not the page's first string)
+    if (i0 == 0) { P[0] = 0; prefix[base] = 0; }      // (the first prefix length is ignored, encodingread.go:427)
+    int sum_s = 0, sum_l = 0, mn = 0x7fffffff, L[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if ((uint32_t)P[k] > (uint32_t)kChainMax || (uint32_t)S[k] > (uint32_t)kChainMax || (uint32_t)(P[k] + S[k]) > (uint32_t)kChainMax) { odd = true; P[k] = 0; S[k] = 0; }
+      L[k] = P[k] + S[k];
+      sum_s += S[k]; sum_l += L[k];
+      if (i0 + k < cnt) mn = P[k] < mn ? P[k] : mn;
+    }
+    // a prefix longer than the string before it: a slice out of range in the reference (encodingread.go:430)
+    int before = __builtin_amdgcn_update_dpp(0, L[3], 0x138, 0xF, 0xF, false);    // wave_shr:1
+    if (lane == 0) before = before0;
+    if (i0 > 0 && i0 < cnt && P[0] > before) odd = true;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if (i0 + k < cnt && P[k] > L[k - 1]) odd = true;
+    // sums and minimum over the 16 lanes of a row, in the row's last lane
+#define PQD_ROW_STEP(CTRL) { \
+      sum_s += __builtin_amdgcn_update_dpp(0, sum_s, CTRL, 0xF, 0xF, false); \
+      sum_l += __builtin_amdgcn_update_dpp(0, sum_l, CTRL, 0xF, 0xF, false); \
+      const int y = __builtin_amdgcn_update_dpp(0x7fffffff, mn, CTRL, 0xF, 0xF, false); \
+      mn = y < mn ? y : mn; }
+    PQD_ROW_STEP(0x111) PQD_ROW_STEP(0x112) PQD_ROW_STEP(0x114) PQD_ROW_STEP(0x118)      // row_shr:1, 2, 4, 8
+#undef PQD_ROW_STEP
+    const int b = i0 >> 6;
+    if ((lane & 15) == 15 && 64 * b < cnt) { blk[base + b] = make_uint2((uint32_t)sum_s, (uint32_t)sum_l); bmin[base + b] = mn; }
   }
   if (__any(odd) && lane == 0) c.chunk_status[kLayoutMismatch] = 1;
 }
@@ -1291,7 +1293,7 @@ hipError_t launch_dba_lean_offsets(const ChunkCtx &c, int32_t *prefix, const int
                                    const int64_t *n_dense, int64_t n_slots, bool tail, int64_t *doff, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   int64_t *page_tot = page_work, *page_base = page_work + c.nd;
-  hipLaunchKernelGGL(k_dba_sums, dim3(c.nd, c.nd > 4096 ? 1 : 16), dim3(256), 0, stream, c, prefix, lens, static_cast<uint2 *>(blk), bmin);
+  hipLaunchKernelGGL(k_dba_sums, dim3(c.nd, c.nd > 4096 ? 1 : 8), dim3(256), 0, stream, c, prefix, lens, static_cast<uint2 *>(blk), bmin);
   hipLaunchKernelGGL(k_dba_page_scan, dim3(c.nd), dim3(256), 0, stream, c, static_cast<uint2 *>(blk), page_tot);
   hipLaunchKernelGGL(k_dba_page_bases, dim3(1), dim3(1024), 0, stream, c.nd, (const int64_t *)page_tot, page_base);
   const int64_t from = tail ? 0 : n_slots;
