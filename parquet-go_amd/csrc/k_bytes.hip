@@ -76,8 +76,7 @@ __global__ void k_plain_ba_walk(ChunkCtx c, const int32_t *__restrict__ dict_pag
 // start), page_base being the payload sizes of the pages in front added up (k_dlba_page_bases).  A page that holds bytes
 // behind its last string makes those sums wrong for every page after it: noted in chunk_status[kLayoutMismatch].
 constexpr int kPairsThreads = 1024;   // (a page is one workgroup's: the more threads, the fewer rounds and barriers)
-template <class LT>     // the decoded lengths: 64-bit words, or 32-bit ones (launch_delta_decode, narrow)
-__global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int encoding, const LT *__restrict__ lens, uint64_t *__restrict__ pairs_out,
+__global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int encoding, const int64_t *__restrict__ lens, uint64_t *__restrict__ pairs_out,
                                                     const int64_t *__restrict__ page_base, int64_t *__restrict__ doff) {
   constexpr int kPer = 4;  // consecutive values per thread and round
   __shared__ int64_t s_wave[kPairsThreads / 64];
@@ -86,9 +85,6 @@ __global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int en
   const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = c.streams[2 * c.nd + d].page;
   if (c.pages[p].encoding != encoding) return;
-  // (32-bit lengths that may not be the reference's 64-bit ones - the delta decode has said so - decide nothing: the call is
-  //  decoded again from 64-bit lengths)
-  if (sizeof(LT) == 4 && c.chunk_status[kLayoutMismatch] != 0) return;
   PageState *ps = &c.state[p];
   if (ps->status != 0 || ps->cnt <= 0) return;
   const int64_t cnt = ps->cnt, base = ps->dense_base;
@@ -137,6 +133,93 @@ __global__ __launch_bounds__(kPairsThreads) void k_dlba_pairs(ChunkCtx c, int en
       doff[base + cnt] = out0 + s_carry;     // (the next page's first offset, or the total)
       if (s_carry != end && !s_refused && !s_bad) c.chunk_status[kLayoutMismatch] = 1;
     }
+  }
+}
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
+__device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return x;
+}
+
+// The offsets of a chunk of DELTA_LENGTH_BYTE_ARRAY pages from 32-bit lengths (launch_delta_decode, narrow): what k_dlba_pairs
+// does with page_base / doff given, four lengths per thread as one vector, the sums of a wavefront by a DPP scan (a
+// wavefront's 256 lengths of at most kMaxStrLen add up to less than 2^32), two 16-byte stores of offsets per thread.
+__global__ __launch_bounds__(kPairsThreads) void k_dlba_offsets32(ChunkCtx c, const int32_t *__restrict__ lens, const int64_t *__restrict__ page_base,
+                                                                int64_t *__restrict__ doff) {
+  __shared__ int64_t s_wave[kPairsThreads / 64];
+  __shared__ int64_t s_carry;
+  __shared__ int s_bad, s_refused;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = c.streams[2 * c.nd + d].page;
+  if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
+  // (32-bit lengths that may not be the reference's 64-bit ones - the delta decode has said so - decide nothing: the call is
+  //  decoded again from 64-bit lengths)
+  if (c.chunk_status[kLayoutMismatch] != 0) return;
+  PageState *ps = &c.state[p];
+  if (ps->status != 0 || ps->cnt <= 0) return;
+  const int64_t cnt = ps->cnt, base = ps->dense_base;
+  const int64_t end = ps->val_off + ps->val_len;
+  const int64_t pay0 = ps->aux0;
+  const int64_t out0 = page_base[d] - pay0;
+  if (tid == 0) { s_carry = pay0; s_bad = 0; s_refused = 0; }
+  __syncthreads();
+  struct I4 { int32_t v[4]; } __attribute__((packed));
+  struct L2 { int64_t v[2]; } __attribute__((packed));
+  for (int64_t i0 = 0; i0 < cnt; i0 += kPairsThreads * 4) {
+    const int64_t carry = s_carry;
+    const int64_t i = i0 + 4 * (int64_t)tid;
+    int32_t ln[4] = {0, 0, 0, 0};
+    if (i + 3 < cnt) {
+      const I4 x = *reinterpret_cast<const I4 *>(lens + base + i);
+#pragma unroll
+      for (int j = 0; j < 4; j++) ln[j] = x.v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (i + j < cnt) ln[j] = lens[base + i + j];
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (ln[j] < 0) { s_bad = 1; ln[j] = 0; }  // make([]byte, huge) panics in the reference
+      if (ln[j] > kMaxStrLen) { s_refused = 1; ln[j] = 0; }
+      sum += (uint32_t)ln[j];
+    }
+    const uint32_t incl = dba_wave_incl_sum(sum);
+    if (lane == 63) s_wave[wave] = (int64_t)incl;
+    __syncthreads();   // also: every thread has read s_carry
+    int64_t src = carry + (int64_t)(incl - sum);
+    for (int k = 0; k < wave; k++) src += s_wave[k];
+    int64_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i + j < cnt && ln[j] > 0 && src + ln[j] > end) s_refused = 1;  // the reference would zero pad a cut string (or hit EOF at the next one)
+      o[j] = out0 + src;
+      src += ln[j];
+    }
+    if (i + 3 < cnt) {
+      *reinterpret_cast<L2 *>(doff + base + i) = L2{{o[0], o[1]}};
+      *reinterpret_cast<L2 *>(doff + base + i + 2) = L2{{o[2], o[3]}};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (i + j < cnt) doff[base + i + j] = o[j];
+    }
+    if (tid == kPairsThreads - 1) s_carry = src;   // the last thread ends where the round ends
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (s_refused) set_status_b(&ps->status, PQD_ERR_REFUSED);
+    else if (s_bad) set_status_b(&ps->status, PQD_ERR_MALFORMED);
+    ps->aux1 = s_carry;  // end of the payload
+    doff[base + cnt] = out0 + s_carry;     // (the next page's first offset, or the total)
+    if (s_carry != end && !s_refused && !s_bad) c.chunk_status[kLayoutMismatch] = 1;
   }
 }
 
@@ -571,17 +654,6 @@ __global__ __launch_bounds__(256) void k_dba_prepare(ChunkCtx c, int64_t *prefix
 // chunk_status[kLayoutMismatch] and the call is decoded again by the kernels that keep a descriptor per value.
 // Block b of a page lies at index dense_base + b of the arrays (a page has fewer blocks than strings).
 // ---------------------------------------------------------------------------------------------
-// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
-__device__ __forceinline__ uint32_t dba_wave_incl_sum(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
-  return x;
-}
-
 // (a thread takes four consecutive strings, so a block of 64 is one row of 16 lanes and its sums are row reductions: four
 //  blocks per wavefront step, a dozen instructions per block)
 __global__ __launch_bounds__(256) void k_dba_sums(ChunkCtx c, int32_t *prefix, const int32_t *__restrict__ lens, uint2 *__restrict__ blk,
@@ -1147,7 +1219,7 @@ hipError_t launch_plain_ba_walk(const ChunkCtx &c, const int32_t *dict_pages, in
 
 hipError_t launch_dlba_pairs(const ChunkCtx &c, int encoding, const int64_t *lens, uint64_t *pairs_out, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dlba_pairs<int64_t>, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
+  hipLaunchKernelGGL(k_dlba_pairs, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, encoding, lens, pairs_out, (const int64_t *)nullptr, (int64_t *)nullptr);
   return hipGetLastError();
 }
 
@@ -1155,8 +1227,7 @@ hipError_t launch_dlba_offsets(const ChunkCtx &c, const int32_t *lens, int64_t *
                                int64_t *doff, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_dlba_page_bases, dim3(1), dim3(1024), 0, stream, c, page_base);
-  hipLaunchKernelGGL(k_dlba_pairs<int32_t>, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, (int)PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, lens, (uint64_t *)nullptr,
-                     (const int64_t *)page_base, doff);
+  hipLaunchKernelGGL(k_dlba_offsets32, dim3(c.nd), dim3(kPairsThreads), 0, stream, c, lens, (const int64_t *)page_base, doff);
   // (a page without values writes nothing: the entries from the last value on are filled in whenever slots can lie behind it,
   //  and index n_slots always)
   const int64_t from = tail ? 0 : n_slots;
