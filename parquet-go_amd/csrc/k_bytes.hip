@@ -561,25 +561,48 @@ __global__ __launch_bounds__(256) void k_copy_values(ChunkCtx c, const uint64_t 
 
 struct V16U { uint32_t v[4]; } __attribute__((packed));
 
-__global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
-                                                         const int64_t *__restrict__ total, int64_t cap) {
-  // grid.x = data pages, grid.y = slices of the page
-  if (*total > cap) return;
-  if (!pairs && c.chunk_status[kLayoutMismatch] != 0) return;     // (offsets that are about to be computed again)
-  const int d = blockIdx.x;
+// A page's strings are one contiguous piece.  k_copy_plan notes per page where it comes from, where it goes and how long it
+// is (nothing for pages that are not copied); the copying workgroups then start with one load instead of a chain of four.
+// Workgroups that follow each other take pieces that follow each other in memory (the piece index is the fast grid
+// dimension): 100 M strings 1.3 ms against 1.6 with the page as the fast dimension and every workgroup striding over
+// its page - the pieces in flight at any moment then lie megabytes apart.
+constexpr int kCopyPiece = 8192;   // bytes per workgroup (grid.x * kCopyPiece covers the longest page)
+struct CopyPlan { int64_t src, dst, n; };
+
+__global__ __launch_bounds__(256) void k_copy_plan(ChunkCtx c, const uint64_t *pairs, const int64_t *doff, const int64_t *__restrict__ total, int64_t cap,
+                                                   CopyPlan *plan) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= c.nd) return;
+  CopyPlan pl{0, 0, 0};
   const int p = c.streams[2 * c.nd + d].page;
-  if (c.pages[p].encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;
   const PageState ps = c.state[p];
-  if (ps.status != 0 || ps.cnt <= 0) return;
-  const int64_t first = ps.dense_base;
-  const uint8_t *src = c.in + (pairs ? (int64_t)(pairs[first] & kSrcMask) : ps.aux0);
-  uint8_t *dst = bytes_out + doff[first];
-  const int64_t n = doff[first + ps.cnt] - doff[first];
+  // (nothing when the output is too small for the call's bytes, or when the offsets are about to be computed again)
+  if (*total <= cap && (pairs || c.chunk_status[kLayoutMismatch] == 0) && c.pages[p].encoding == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && ps.status == 0 &&
+      ps.cnt > 0) {
+    const int64_t first = ps.dense_base;
+    pl.src = pairs ? (int64_t)(pairs[first] & kSrcMask) : ps.aux0;
+    pl.dst = doff[first];
+    pl.n = doff[first + ps.cnt] - doff[first];
+  }
+  plan[d] = pl;
+}
+
+__global__ __launch_bounds__(256) void k_copy_dlba_pages(ChunkCtx c, const CopyPlan *__restrict__ plan, uint8_t *bytes_out, int strided) {
+  const CopyPlan pl = plan[strided ? blockIdx.x : blockIdx.y];
+  const int64_t n = pl.n;
+  const int64_t piece0 = strided ? 0 : (int64_t)blockIdx.x * kCopyPiece;
+  if (piece0 >= n) return;
+  const uint8_t *src = c.in + pl.src;
+  uint8_t *dst = bytes_out + pl.dst;
   // The stores are aligned (whole lines leave a wavefront), the loads take whatever alignment that leaves them: the first
   // bytes up to the output's next 16-byte boundary are copied one by one.
   const int64_t head = n < 16 ? n : (int64_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
-  if (blockIdx.y == 0 && threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
-  for (int64_t b = head + ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; b < n; b += (int64_t)gridDim.y * 256 * 16) {
+  const bool first_piece = strided ? blockIdx.y == 0 : blockIdx.x == 0;
+  if (first_piece && threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+  int64_t b, step, lim;
+  if (!strided) { b = head + piece0 + threadIdx.x * 16; step = 256 * 16; lim = head + piece0 + kCopyPiece; if (lim > n) lim = n; }
+  else { b = head + ((int64_t)blockIdx.y * 256 + threadIdx.x) * 16; step = (int64_t)gridDim.y * 256 * 16; lim = n; }     // (more pages than grid.y allows)
+  for (; b < lim; b += step) {
     if (b + 16 <= n) {
       const V16U x = *reinterpret_cast<const V16U *>(src + b);
       *reinterpret_cast<uint4 *>(dst + b) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
@@ -1334,10 +1357,18 @@ hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const in
   return hipGetLastError();
 }
 
+size_t copy_plan_bytes(int nd) { return sizeof(CopyPlan) * ((size_t)nd + 1); }
+
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
-                                  const int64_t *total, int64_t cap, hipStream_t stream) {
+                                  const int64_t *total, int64_t cap, int64_t max_page_bytes, void *plan, hipStream_t stream) {
   if (c.nd <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_copy_dlba_pages, dim3(c.nd, c.nd > 4096 ? 2 : 32), dim3(256), 0, stream, c, pairs, doff, bytes_out, total, cap);
+  CopyPlan *pl = static_cast<CopyPlan *>(plan);
+  hipLaunchKernelGGL(k_copy_plan, dim3((c.nd + 255) / 256), dim3(256), 0, stream, c, pairs, doff, total, cap, pl);
+  const int64_t pieces = (max_page_bytes + 16 + kCopyPiece - 1) / kCopyPiece;
+  if (c.nd <= 65535 && pieces >= 1 && pieces <= 0x7FFFFFFF)
+    hipLaunchKernelGGL(k_copy_dlba_pages, dim3((unsigned)pieces, c.nd), dim3(256), 0, stream, c, (const CopyPlan *)pl, bytes_out, 0);
+  else
+    hipLaunchKernelGGL(k_copy_dlba_pages, dim3(c.nd, 2), dim3(256), 0, stream, c, (const CopyPlan *)pl, bytes_out, 1);
   return hipGetLastError();
 }
 

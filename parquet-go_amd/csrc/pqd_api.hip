@@ -204,6 +204,7 @@ struct pqd_handle {
     bool fast_dlba = false;     // DELTA_LENGTH_BYTE_ARRAY pages only, offsets straight from the decoded lengths: no pairs
     bool fast_dba = false;      // DELTA_BYTE_ARRAY pages only: offsets and sources from sums per 64 strings, no pairs
     int64_t slots = 0;
+    int64_t max_page_bytes = 0; // the longest data page
   } plan;
 
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;  // hand-over to and from the device's shared stream
@@ -301,6 +302,9 @@ constexpr int kSmallByteTotal = 16;    // int64 index: byte total of a BYTE_ARRA
 // (2 nd + 2) int64 words behind the page flags: output bytes and output base of every page of a chunk of DELTA_BYTE_ARRAY pages only
 int64_t *dba_page_work(pqd_handle *h) { return reinterpret_cast<int64_t *>(static_cast<uint8_t *>(h->dba_flags.p) + align_up(4 * (size_t)h->nd + 64, 256)); }
 
+// copy_plan_bytes(nd) bytes behind them: what the copy of DELTA_LENGTH_BYTE_ARRAY pages notes per page
+void *copy_plan(pqd_handle *h) { return static_cast<uint8_t *>(h->dba_flags.p) + align_up(4 * (size_t)h->nd + 64, 256) + align_up(8 * (2 * (size_t)h->nd + 2) + 64, 256); }
+
 // The byte copies of a BYTE_ARRAY call, against the current capacity of h->bytes.
 int launch_byte_copies(pqd_handle *h) {
   const pqd_handle::BytesPlan &pl = h->plan;
@@ -316,7 +320,7 @@ int launch_byte_copies(pqd_handle *h) {
     Prof pf(h, "k_copy_values");
     HIP_TRY(launch_copy_values(c, pairs, doff, all_dlba ? 1 : 0, bytes_out, d_total, cap, h->stream));
   }
-  if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pl.fast_dlba ? nullptr : pairs, doff, bytes_out, d_total, cap, h->stream)); }
+  if (all_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pl.fast_dlba ? nullptr : pairs, doff, bytes_out, d_total, cap, pl.max_page_bytes, copy_plan(h), h->stream)); }
   if (pl.fast_dba) {
     Prof pf(h, "k_dba_chain");
     HIP_TRY(launch_dba_lean_chain(c, reinterpret_cast<const int32_t *>(prefix64), static_cast<const int32_t *>(h->lens64.p), h->pairs.p, static_cast<const int32_t *>(h->parent.p),
@@ -364,7 +368,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   h->h_pages = HostSpan<PageIn>{static_cast<PageIn *>(h->stage_meta.p), (size_t)n_pages};
   h->h_dict_pages.clear();
   int nd = 0;
-  int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0, lv_runs = 0, lv_tiles = 0;
+  int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0, lv_runs = 0, lv_tiles = 0, max_page_bytes = 0;
   int host_status = PQD_OK, host_bad = -1;
   bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_rle = false;
   bool any_dlba = false, any_dba = false;
@@ -386,6 +390,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       if (d.page_type == PQD_DATA_PAGE || d.page_type == PQD_DATA_PAGE_V2) {
         pi.data_idx = nd++;
         data_bytes += d.length;
+        if (d.length > max_page_bytes) max_page_bytes = d.length;
         if (d.num_values > 0) slots += d.num_values;
         {   // what a level stream of the page takes in the run table and the tile table
           const int64_t nv = d.num_values > 0 ? d.num_values : 0;
@@ -547,7 +552,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (any_dlba || any_dba) {   // FIXED_LEN_BYTE_ARRAY pages under the delta byte-array encodings: the work arrays of the BYTE_ARRAY path
       const size_t n8 = 8 * ((size_t)slots + 2) + 64;
       if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->lens64.ensure(n8))) return rc;
-      if (any_dba && ((rc = h->dba_flags.ensure(4 * (size_t)nd + 64)) || (rc = h->prefix64.ensure(n8)) ||
+      if ((rc = h->dba_flags.ensure(align_up(4 * (size_t)nd + 64, 256) + align_up(8 * (2 * (size_t)nd + 2) + 64, 256) + copy_plan_bytes(nd) + 64))) return rc;
+      if (any_dba && ((rc = h->prefix64.ensure(n8)) ||
                       (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
     }
   } else {
@@ -557,7 +563,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (any_dba && ((rc = h->prefix64.ensure(n8)) || (rc = h->parent.ensure(4 * ((size_t)slots + 2) + 64)))) return rc;
     if (any_dlba && (rc = h->parent.ensure(8 * ((size_t)nd + 2) + 64))) return rc;      // (page bases of a chunk of DELTA_LENGTH_BYTE_ARRAY pages only)
     if ((rc = h->scratch.ensure(std::max<size_t>(8 * ((size_t)(slots + 1 + 4095) / 2048 + 8) + 64, len_scan_work_bytes(slots) + 64)))) return rc;
-    if ((rc = h->dba_flags.ensure(align_up(4 * (size_t)nd + 64, 256) + 8 * (2 * (size_t)nd + 2) + 64))) return rc;
+    if ((rc = h->dba_flags.ensure(align_up(4 * (size_t)nd + 64, 256) + align_up(8 * (2 * (size_t)nd + 2) + 64, 256) + copy_plan_bytes(nd) + 64))) return rc;
     // the byte output: every PLAIN / DELTA_LENGTH value lies inside its page, so the page bytes bound it; dictionary
     // and DELTA_BYTE_ARRAY pages may expand beyond that and are then copied again by pqd_wait
     if ((rc = h->bytes.ensure((size_t)all_bytes + 64))) return rc;
@@ -801,7 +807,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     HIP_TRY(hipMemcpyAsync(d_totals + kSmallByteTotal, doff + slots, 8, hipMemcpyDeviceToDevice, h->stream));
     h->plan.active = true; h->plan.any_plain = any_plain; h->plan.any_dict_enc = any_dict_enc; h->plan.any_dlba = any_dlba;
-    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots; h->plan.fast_dlba = fast_dlba; h->plan.fast_dba = fast_dba;
+    h->plan.any_dba = any_dba; h->plan.nullable = nullable; h->plan.slots = slots; h->plan.fast_dlba = fast_dlba; h->plan.fast_dba = fast_dba; h->plan.max_page_bytes = max_page_bytes;
     if ((rc = launch_byte_copies(h))) return rc;
     if (nullable) {
       const int n_tiles = (int)((slots + 1 + 4095) / 4096);
@@ -859,7 +865,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       }
       { Prof pf(h, "k_flba_delta_check"); HIP_TRY(launch_flba_delta_offsets(c, pairs, any_dba ? prefix64 : nullptr, slots, doff, h->stream)); }
       const int64_t cap = slots * (int64_t)esz;
-      if (any_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, dense_out, doff + slots, cap, h->stream)); }
+      if (any_dlba) { Prof pf(h, "k_copy_dlba_pages"); HIP_TRY(launch_copy_dlba_pages(c, pairs, doff, dense_out, doff + slots, cap, max_page_bytes, copy_plan(h), h->stream)); }
       if (any_dba) { Prof pf(h, "k_dba_resolve");
         HIP_TRY(launch_dba_resolve(c, prefix64, pairs, static_cast<int32_t *>(h->parent.p), doff, static_cast<int32_t *>(h->dba_flags.p), dense_out, 1, doff + slots, cap, h->stream)); }
     }

@@ -106,8 +106,10 @@ hipError_t launch_flba_delta_offsets(const ChunkCtx &c, const uint64_t *pairs, c
 hipError_t launch_copy_values(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, int flat_dlba, uint8_t *bytes_out,
                               const int64_t *total, int64_t cap, hipStream_t stream);
 // (pairs == nullptr: a page's bytes start where its length stream ended)
+// max_page_bytes: at least the longest page's bytes (sets the grid); plan: copy_plan_bytes(nd) bytes of work space
+size_t copy_plan_bytes(int nd);
 hipError_t launch_copy_dlba_pages(const ChunkCtx &c, const uint64_t *pairs, const int64_t *doff, uint8_t *bytes_out,
-                                  const int64_t *total, int64_t cap, hipStream_t stream);
+                                  const int64_t *total, int64_t cap, int64_t max_page_bytes, void *plan, hipStream_t stream);
 // A chunk of DELTA_BYTE_ARRAY pages only: offsets and suffix positions from sums per 64 strings (blk: 8 bytes per value slot,
 // bmin: 4 bytes per value slot, page_work: (2 nd + 2) * 8 bytes); chunk_status[kLayoutMismatch] is set when a page is not
 // clean, and the call is then decoded by the kernels that keep a descriptor per value.
