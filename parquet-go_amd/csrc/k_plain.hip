@@ -469,29 +469,52 @@ __global__ __launch_bounds__(1024) void k_scatter_scan_cnt(const int32_t *cnt, i
 // A workgroup takes a tile, a wavefront 1024 of its slots (32 words of bits): lane l holds the popcount of word l, a wave
 // scan gives every word its rank, and the wavefront then walks its slots 64 at a time - lane l takes slot 64 j + l - so that
 // neighbouring lanes read neighbouring values from the page and write neighbouring slots.
-template <int ESZ>
-__global__ __launch_bounds__(256) void k_scatter_bits_plain(ChunkCtx c, const int32_t *__restrict__ tile_prefix, const int32_t *__restrict__ tile_stream,
-                                                            int def_tile0, const uint32_t *__restrict__ bits, const int64_t *__restrict__ partial,
-                                                            uint8_t *out) {
-  typedef typename std::conditional<ESZ == 8, uint64_t, uint32_t>::type T;
-  struct TU { T v; } __attribute__((packed));
-  __shared__ int s_wave[4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int dt = blockIdx.x;
+// What a tile's workgroup needs, worked out for all tiles at once by k_scatter_bits_plan (page of the tile, its first tile,
+// the rank of the tile's first value): the scatter itself then starts with one load instead of a chain of four.
+struct ScatterPlan {
+  int64_t src;        // chunk offset of the value of rank 0 of the tile (the page's value section + the values in front of the tile)
+  int64_t out_slot;   // slot of the tile's first value in the column image
+  int32_t left;       // bytes of the value section from `src` on (may be negative when the page is too short)
+  int32_t n;          // slots of the tile (0: nothing to do)
+};
+
+__global__ __launch_bounds__(256) void k_scatter_bits_plan(ChunkCtx c, const int32_t *__restrict__ tile_prefix, const int32_t *__restrict__ tile_stream,
+                                                           int def_tile0, int n_def_tiles, const int64_t *__restrict__ partial, ScatterPlan *plan) {
+  const int dt = blockIdx.x * 256 + threadIdx.x;
+  if (dt >= n_def_tiles) return;
   const int ls = tile_stream[def_tile0 + dt];            // the definition-level stream (index among the level streams)
-  const Stream *sp = &c.streams[ls];
-  const int p = sp->page;
+  const int p = c.streams[ls].page;
   const int first = tile_prefix[ls] - def_tile0;         // the page's first definition-level tile
   const int t0 = (dt - first) * kScatterTile;
   const PageState *ps = &c.state[p];
-  if (dt == first && tid == 0 && ps->status == 0 && c.pages[p].encoding == PQD_ENC_PLAIN) {
+  if (dt == first && ps->status == 0 && c.pages[p].encoding == PQD_ENC_PLAIN) {
     // (the page's length is checked the way the copying kernel does, binaryread.go:12-18)
     const int st = plain_fixed_status(c.physical_type, ps->val_len, ps->cnt, c.elem_size);
     if (st) set_status1(&c.state[p].status, st);
   }
   const int n = c.pages[p].num_values > 0 ? c.pages[p].num_values : 0;
-  if (t0 >= n) return;
+  ScatterPlan pl{0, 0, 0, 0};
+  if (t0 < n) {
+    const int64_t r0 = (partial[dt] - partial[first]) * c.elem_size;
+    pl.src = ps->val_off + r0;
+    const int64_t left = ps->val_len - r0;
+    pl.left = left > 0x7fffffff ? 0x7fffffff : (left < -0x7fffffff ? -0x7fffffff : (int32_t)left);
+    pl.out_slot = c.pages[p].slot_base + t0;
+    pl.n = n - t0 < kScatterTile ? n - t0 : kScatterTile;
+  }
+  plan[dt] = pl;
+}
+
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_scatter_bits_plain(ChunkCtx c, const ScatterPlan *__restrict__ plan, const uint32_t *__restrict__ bits, uint8_t *out) {
+  typedef typename std::conditional<ESZ == 8, uint64_t, uint32_t>::type T;
+  struct TU { T v; } __attribute__((packed));
+  __shared__ int s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dt = blockIdx.x;
+  const ScatterPlan pl = plan[dt];
   const uint32_t word = lane < 32 ? bits[(size_t)dt * (kScatterTile / 32) + wv * 32 + lane] : 0u;
+  if (pl.n <= 0) return;
   const int cw = __builtin_popcount(word);
   int incl = cw;
   for (int o = 1; o < 32; o <<= 1) {
@@ -505,33 +528,44 @@ __global__ __launch_bounds__(256) void k_scatter_bits_plain(ChunkCtx c, const in
 #pragma unroll
   for (int q = 0; q < 4; q++) if (q < wv) wbase += s_wave[q];
   const int excl = incl - cw;                                         // values in the wavefront's words before word `lane`
-  const int64_t r0 = (partial[dt] - partial[first]) + wbase;          // rank, among the page's values, of the wavefront's first
-  const int64_t val_len = ps->val_len;
-  const uint8_t *src = c.in + ps->val_off;
-  T *o = reinterpret_cast<T *>(out) + c.pages[p].slot_base + t0 + wv * 1024;
-  const int left = n - (t0 + wv * 1024);                              // slots of the page from the wavefront's first on
-  const uint32_t below = (1u << (lane & 31)) - 1u;
+  const uint8_t *src = c.in + pl.src;
+  const int64_t val_left = pl.left;
+  T *o = reinterpret_cast<T *>(out) + pl.out_slot + wv * 1024;
+  const int left = pl.n - wv * 1024;                                  // slots of the tile from the wavefront's first on
+  // a lane takes two neighbouring slots: a store instruction of the wavefront leaves 128 slots (1 KiB of 64-bit values) without gaps
+  const uint32_t sh = 2u * (uint32_t)(lane & 15);
+  const uint32_t below = (1u << sh) - 1u;
+  struct T2 { T a, b; } __attribute__((packed));
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const int wi = 2 * j + (lane >> 5);
+  for (int j = 0; j < 8; j++) {
+    const int wi = 4 * j + (lane >> 4);
     const uint32_t wj = (uint32_t)__shfl((int)word, wi);
     const int ej = __shfl(excl, wi);
-    const bool v = (wj >> (lane & 31)) & 1u;
-    const int64_t off = (r0 + ej + __builtin_popcount(wj & below)) * ESZ;
+    const bool v0 = (wj >> sh) & 1u, v1 = (wj >> (sh + 1u)) & 1u;
+    const int64_t off0 = (int64_t)(wbase + ej + __builtin_popcount(wj & below)) * ESZ;
+    const int64_t off1 = off0 + (v0 ? ESZ : 0);
     // (a page that is too short has failed; its slots only must not be read from beyond it)
-    const T y = (v && off + ESZ <= val_len) ? reinterpret_cast<const TU *>(src + off)->v : (T)0;
-    if (64 * j + lane < left) reinterpret_cast<TU *>(o + 64 * j + lane)->v = y;
+    const T y0 = (v0 && off0 + ESZ <= val_left) ? reinterpret_cast<const TU *>(src + off0)->v : (T)0;
+    const T y1 = (v1 && off1 + ESZ <= val_left) ? reinterpret_cast<const TU *>(src + off1)->v : (T)0;
+    const int s0 = 128 * j + 2 * lane;
+    if (s0 + 1 < left) *reinterpret_cast<T2 *>(o + s0) = T2{y0, y1};
+    else if (s0 < left) reinterpret_cast<TU *>(o + s0)->v = y0;
   }
 }
 
+size_t scatter_plan_bytes(int n_def_tiles) { return sizeof(ScatterPlan) * ((size_t)n_def_tiles + 1); }
+
 hipError_t launch_scatter_plain_bits(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int def_tile0, int n_def_tiles,
-                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, uint8_t *out, hipStream_t stream) {
+                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, void *plan, uint8_t *out, hipStream_t stream) {
   if (n_def_tiles <= 0) return hipSuccess;
+  ScatterPlan *pl = static_cast<ScatterPlan *>(plan);
   hipLaunchKernelGGL(k_scatter_scan_cnt, dim3(1), dim3(1024), 0, stream, valid_cnt, partial, n_def_tiles);
+  hipLaunchKernelGGL(k_scatter_bits_plan, dim3((n_def_tiles + 255) / 256), dim3(256), 0, stream, c, tile_prefix, tile_stream, def_tile0, n_def_tiles,
+                     (const int64_t *)partial, pl);
   if (c.elem_size == 4)
-    hipLaunchKernelGGL(k_scatter_bits_plain<4>, dim3(n_def_tiles), dim3(256), 0, stream, c, tile_prefix, tile_stream, def_tile0, valid_bits, partial, out);
+    hipLaunchKernelGGL(k_scatter_bits_plain<4>, dim3(n_def_tiles), dim3(256), 0, stream, c, (const ScatterPlan *)pl, valid_bits, out);
   else
-    hipLaunchKernelGGL(k_scatter_bits_plain<8>, dim3(n_def_tiles), dim3(256), 0, stream, c, tile_prefix, tile_stream, def_tile0, valid_bits, partial, out);
+    hipLaunchKernelGGL(k_scatter_bits_plain<8>, dim3(n_def_tiles), dim3(256), 0, stream, c, (const ScatterPlan *)pl, valid_bits, out);
   return hipGetLastError();
 }
 

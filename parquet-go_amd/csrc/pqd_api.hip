@@ -548,7 +548,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if ((slots > 0 || !h->values.fixed) && (rc = h->values.ensure(val_bytes))) return rc;   // (a chunk without slots writes no values: a caller may pass none)
     if (nullable && (rc = h->dense.ensure(val_bytes))) return rc;
     if (nullable && slots > 0 && (rc = h->scratch.ensure(12 * ((size_t)((slots + 4095) / 4096) + (size_t)n_def_tiles) + 128))) return rc;
-    if (scatter_bits && (rc = h->lvbits.ensure((size_t)n_def_tiles * (kTile / 8 + 4) + 64))) return rc;
+    if (scatter_bits && (rc = h->lvbits.ensure(align_up((size_t)n_def_tiles * (kTile / 8 + 4) + 64, 256) + scatter_plan_bytes(n_def_tiles) + 64))) return rc;
     if (any_dlba || any_dba) {   // FIXED_LEN_BYTE_ARRAY pages under the delta byte-array encodings: the work arrays of the BYTE_ARRAY path
       const size_t n8 = 8 * ((size_t)slots + 2) + 64;
       if ((rc = h->pairs.ensure(n8)) || (rc = h->doff.ensure(n8)) || (rc = h->lens64.ensure(n8))) return rc;
@@ -874,7 +874,9 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       if (scatter_bits)
         HIP_TRY(launch_scatter_plain_bits(c, d_tp_lv, d_ts_lv, tp_levels[(size_t)nd], n_def_tiles, static_cast<const uint32_t *>(h->lvbits.p),
                                           reinterpret_cast<const int32_t *>(static_cast<const uint8_t *>(h->lvbits.p) + (size_t)n_def_tiles * (kTile / 8)),
-                                          static_cast<int64_t *>(h->scratch.p), static_cast<uint8_t *>(h->values.p), h->stream));
+                                          static_cast<int64_t *>(h->scratch.p),
+                                          static_cast<uint8_t *>(h->lvbits.p) + align_up((size_t)n_def_tiles * (kTile / 8 + 4) + 64, 256),
+                                          static_cast<uint8_t *>(h->values.p), h->stream));
       else if (plain_scatter)
         HIP_TRY(launch_scatter_plain(c, static_cast<const int32_t *>(h->def.p), static_cast<uint8_t *>(h->values.p), slots,
                                      static_cast<int64_t *>(h->scratch.p), h->stream));

@@ -62,8 +62,10 @@ hipError_t launch_scatter_plain(const ChunkCtx &c, const int32_t *def_levels, ui
                                 hipStream_t stream);
 // the same from the validity bits the level expansion left per definition-level tile: the levels are not read again
 // (tile_prefix / tile_stream: the level tiles' tables; n_def_tiles tiles from def_tile0 on; partial: n_def_tiles + 1 int64)
+// plan: scatter_plan_bytes(n_def_tiles) bytes of work space
+size_t scatter_plan_bytes(int n_def_tiles);
 hipError_t launch_scatter_plain_bits(const ChunkCtx &c, const int32_t *tile_prefix, const int32_t *tile_stream, int def_tile0, int n_def_tiles,
-                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, uint8_t *out, hipStream_t stream);
+                                     const uint32_t *valid_bits, const int32_t *valid_cnt, int64_t *partial, void *plan, uint8_t *out, hipStream_t stream);
 
 // ---- k_delta.hip ----
 // one wavefront per page whose value encoding is `encoding`; elem_size 4 or 8; src_sel 1 continues at the end of
