@@ -110,6 +110,25 @@ __global__ __launch_bounds__(256) void k_plain_fixed(PlainArgs a) {
   }
 }
 
+// The same with the grid laid out by page and piece (grid.x = pieces of kPlainTile bytes, enough for the longest page;
+// grid.y = data page): no search for a tile's page, and workgroups that follow each other copy pieces that follow each
+// other in memory.
+__global__ __launch_bounds__(256) void k_plain_fixed_pages(ChunkCtx c, uint8_t *values_out) {
+  const int p = c.streams[2 * c.nd + blockIdx.y].page;
+  const PageState *ps = &c.state[p];
+  if (ps->status != 0 || c.pages[p].encoding != PQD_ENC_PLAIN) return;
+  const int64_t cnt = ps->cnt;
+  const int64_t bytes = cnt * (int64_t)c.elem_size;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int st = plain_fixed_status(c.physical_type, ps->val_len, cnt, c.elem_size);
+    if (st) set_status1(&c.state[p].status, st);
+  }
+  const int64_t first = (int64_t)blockIdx.x * kPlainTile;
+  if (first >= bytes) return;
+  block_copy_tile(c.in + ps->val_off, ps->val_len, values_out + ps->dense_base * (int64_t)c.elem_size, bytes, first, kPlainTile,
+                  c.physical_type == PQD_INT96 ? 12 : 0);
+}
+
 // ---- data pages, BYTE_STREAM_SPLIT FLOAT / DOUBLE: byte k of value i sits at cnt*k + i ----
 // encoding/encodingread.go:437-485: one io.ReadFull of cnt*size bytes, then the byte-plane transpose.
 // A thread assembles four consecutive values from one 4-byte read per plane.
@@ -623,9 +642,15 @@ hipError_t launch_dict_plain_fixed(const ChunkCtx &c, const int32_t *dict_pages,
   return hipGetLastError();
 }
 
-hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, int64_t max_page_bytes, uint8_t *values_out,
                               hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
+  const int64_t pieces = (max_page_bytes + kPlainTile - 1) / kPlainTile;
+  // (many small pages: most workgroups of a page-by-piece grid would find nothing to do)
+  if (c.nd <= 65535 && pieces >= 1 && pieces <= 0x7FFFFFFF && pieces * (int64_t)c.nd <= 2 * (int64_t)n_tiles + 1024) {
+    hipLaunchKernelGGL(k_plain_fixed_pages, dim3((unsigned)pieces, c.nd), dim3(256), 0, stream, c, values_out);
+    return hipGetLastError();
+  }
   PlainArgs a{c, tile_prefix, n_tiles, values_out};
   int grid = n_tiles < 256 * 16 ? n_tiles : 256 * 16;
   hipLaunchKernelGGL(k_plain_fixed, dim3(grid), dim3(256), 0, stream, a);

@@ -831,7 +831,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     }
     if (any_plain && !plain_scatter) {
       if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-      else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+      else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), max_page_bytes, dense_out, h->stream)); }
     }
     if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
     if (any_delta) {

@@ -43,7 +43,7 @@ hipError_t launch_expand_dict(const ChunkCtx &c, const int32_t *tile_prefix, con
 // ---- k_plain.hip ----
 // dict_pages: device list of the call's dictionary pages (page indices)
 hipError_t launch_dict_plain_fixed(const ChunkCtx &c, const int32_t *dict_pages, int n_dict, uint8_t *dict_out, hipStream_t stream);
-hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
+hipError_t launch_plain_fixed(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, int64_t max_page_bytes, uint8_t *values_out,
                               hipStream_t stream);
 hipError_t launch_byte_stream_split(const ChunkCtx &c, const int32_t *tile_prefix, int n_tiles, uint8_t *values_out,
                                     hipStream_t stream);
