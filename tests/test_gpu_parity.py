@@ -1322,6 +1322,70 @@ def test_flba_delta_string_of_another_length_is_refused(dec, oracle, enc):
     assert g.status == -4 and g.bad_page == 0
 
 
+def test_string_lengths_that_do_not_fit_32_bits(dec, oracle):
+    # chunks of one delta string encoding decode their lengths with 32-bit arithmetic where the block headers prove that
+    # to be what the reference's 64-bit arithmetic gives; lengths and prefix lengths whose low words look harmless but
+    # whose 64-bit values are not (2^32 + 2 where 2 bytes are there, steps of 2^32), and honest lengths with large
+    # jumps, must come out as the oracle has them on either path
+    rng = np.random.default_rng(909)
+    good = rand_strings(rng, 300, 0, 40)
+    strs = rand_strings(rng, 200, 1, 30)
+    lens = np.array([len(x) for x in strs], np.int64)
+    payload = b"".join(strs)
+
+    def dlba_chunk(body, n):
+        cb = pg.ChunkBuilder(gap=1, lead=3)
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, len(good), pg.dlba_encode(good))
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, n, body)
+        cb.data_page_v1(pg.ENC_DELTA_LENGTH_BYTE_ARRAY, len(good), pg.dlba_encode(good))
+        return cb.finish()
+
+    cases = []
+    for at, add in ((100, 1 << 32), (0, 1 << 32), (150, -(1 << 32)), (7, 1 << 40)):
+        bad = lens.copy(); bad[at] += add
+        cases.append(dlba_chunk(pg.delta_encode(bad, np.int64) + payload, len(strs)))
+    # every length 2^32 too large: the steps are small, the first value is not
+    cases.append(dlba_chunk(pg.delta_encode(lens + (1 << 32), np.int64) + payload, len(strs)))
+    # honest lengths with jumps of a megabyte
+    big = [b"x" * (1 << 20) if i % 50 == 7 else strs[i] for i in range(len(strs))]
+    cases.append(dlba_chunk(pg.dlba_encode(big), len(big)))
+    # DELTA_BYTE_ARRAY: a prefix length of 2^32 + 1, suffix lengths 2^32 too large
+    keys = sorted(rand_strings(rng, 200, 4, 30))
+    body = pg.dba_encode(keys)
+    pre, suf, prev = [], [], b""
+    for x in keys:
+        k = 0
+        while k < min(len(prev), len(x)) and prev[k] == x[k]:
+            k += 1
+        pre.append(k); suf.append(x[k:]); prev = x
+    for which in (0, 1):
+        p64 = np.array(pre, np.int64); s64 = np.array([len(x) for x in suf], np.int64)
+        if which == 0: p64[120] += 1 << 32
+        else: s64[33] += 1 << 32
+        cb = pg.ChunkBuilder(gap=1, lead=3)
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(keys), body)
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(keys), pg.delta_encode(p64, np.int64) + pg.delta_encode(s64, np.int64) + b"".join(suf))
+        cb.data_page_v1(pg.ENC_DELTA_BYTE_ARRAY, len(keys), body)
+        cases.append(cb.finish())
+    n_ok = 0
+    for chunk, pages in cases:
+        o = oracle.read_chunk(chunk, pages, pg.BYTE_ARRAY, 0, 0, 0)
+        res = []
+        for offsets in (1, 0):
+            dec.set_option(8, offsets)
+            if o.status == 0:
+                g, _ = check_same(dec, oracle, chunk, pages, pg.BYTE_ARRAY)
+                n_ok += 1
+            else:
+                # (a length of 16 MiB or more is refused where the reference reads on to the end of the page: the page and
+                #  the verdict must be the same on both paths, and the reference's where the library has no rule of its own)
+                g = dec.decode(chunk, pages, pg.BYTE_ARRAY)
+                assert g.bad_page == o.bad_page == 1 and g.status in (o.status, -13)
+            res.append((g.status, g.bad_page))
+        assert res[0] == res[1]
+    assert n_ok == 2     # (the honest one, on both paths)
+
+
 def test_delta_length_pages_with_bad_lengths_and_short_payloads(dec, oracle):
     # a chunk of DELTA_LENGTH_BYTE_ARRAY pages only takes its offsets straight from the decoded lengths; what the
     # per-value path checks must still be found, page by page: a negative length (make([]byte, n) panics in the
