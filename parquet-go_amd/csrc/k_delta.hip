@@ -527,7 +527,10 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
   // reach past the stream's last dword are not read: that dword's vector comes in dword by dword, the rest is zero.
   uint32_t *win32 = reinterpret_cast<uint32_t *>(s_win);
   uint32_t wpos = 0, mis = 0;
-  auto stage = [&](uint32_t p) {
+  int wvec = 0;          // vectors of the window that are in place (the first window is a short one: a page whose blocks turn out one
+                         // length long needs the stream's header and its first block header, nothing else)
+  auto stage = [&](uint32_t p, int n_vec) {
+    wvec = n_vec;
     mis = (uint32_t)(reinterpret_cast<uintptr_t>(src + p) & 15u);
     wpos = p;
     const uint8_t *wsrc = src + p - mis;
@@ -536,18 +539,20 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     __syncthreads();       // (one wavefront: the reads of the window before are done)
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
+      if (k > 0 && n_vec <= 64) break;       // (the short first window: one vector per lane)
       const uint8_t *a = wsrc + 16 * (lane + 64 * k);
-      const bool ok = lane + 64 * k < kWalkWinVec && a + 12 <= in_last;
+      const bool ok = lane + 64 * k < n_vec && a + 12 <= in_last;
       v[k] = *reinterpret_cast<const uint4 *>(ok ? a : c.in);     // (an unconditional load: with branches around the loads each one is waited for)
     }
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
       const uint8_t *a = wsrc + 16 * (lane + 64 * k);
       const bool ok = a + 12 <= in_last;
-      if (lane + 64 * k < kWalkWinVec) s_win[lane + 64 * k] = ok ? v[k] : make_uint4(0u, 0u, 0u, 0u);
+      if (k > 0 && n_vec <= 64) break;
+      if (lane + 64 * k < n_vec) s_win[lane + 64 * k] = ok ? v[k] : make_uint4(0u, 0u, 0u, 0u);
     }
     const uint8_t *tail = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(in_last) & ~(uintptr_t)15);   // the vector of the last dword
-    if (tail >= wsrc && tail < wsrc + 16 * kWalkWinVec && tail + 12 > in_last && lane < 4 && tail + 4 * lane <= in_last)
+    if (tail >= wsrc && tail < wsrc + 16 * n_vec && tail + 12 > in_last && lane < 4 && tail + 4 * lane <= in_last)
       win32[(tail - wsrc) / 4 + lane] = *reinterpret_cast<const uint32_t *>(tail + 4 * lane);
     __syncthreads();
   };
@@ -555,7 +560,7 @@ __device__ __forceinline__ int64_t delta_walk(const ChunkCtx &c, const PageIn &p
     const uint32_t r = p - wpos + mis;
     return (win32[r >> 2] >> (8u * (r & 3u))) & 0xFFu;
   };
-  stage(0);
+  stage(0, 64);
 
   // stream header: four varints, parsed by every lane alike
   uint32_t q = 0;
@@ -651,7 +656,7 @@ walk:
   uint32_t pos = q, guess = 0;
   uint32_t b0 = 0;
   while (b0 < n_blocks) {
-    if ((uint64_t)pos - wpos + mis + 20 > (uint64_t)kWalkWinVec * 16u) stage(pos);     // (the first window is in place already)
+    if (wvec < kWalkWinVec || (uint64_t)pos - wpos + mis + 20 > (uint64_t)kWalkWinVec * 16u) stage(pos, kWalkWinVec);
     for (;;) {
       const uint32_t blk = b0 + (uint32_t)lane;
       const uint64_t pj64 = (uint64_t)pos + (uint64_t)(uint32_t)lane * guess;
