@@ -6,8 +6,8 @@
 // ReadPageRawData (:395), (*Page).GetRLDLFromRawData (:433), (*Page).GetValueFromRawData (:562) - with their
 // signatures, results and error values unchanged, so reader/columnbuffer.go and reader/columnreader.go compile and
 // run as they are.  The reference's own definitions of the four stay in the package under private names (readPageCPU,
-// readPageRawDataCPU, getRLDLFromRawDataCPU, getValueFromRawDataCPU: page_read_cpu.go, compiled under both tags, see
-// INTEGRATION.md) and this file hands every chunk it does not take to them: compressed chunks (the reference's writer
+// readPageRawDataCPU, getRLDLFromRawDataCPU, getValueFromRawDataCPU: a file page_read_cpu.go that is compiled under both
+// tags) and this file hands every chunk it does not take to them: compressed chunks (the reference's writer
 // compresses with SNAPPY unless told otherwise, writer/writer.go:63-65) and chunks holding a page the library answers
 // with PQD_ERR_UNSUPPORTED_*, PQD_ERR_BIT_WIDTH, PQD_ERR_NO_DICTIONARY or PQD_ERR_REFUSED.  A build with the tag reads
 // every file the reference reads.
