@@ -260,14 +260,16 @@ __device__ __forceinline__ void expand_items(const ExpandArgs &a, const TileDesc
 
       if (MODE == 0) {
         const uint32_t cmp = is_def ? (uint32_t)c.max_def : 0u;
+        // (one bit per value: which of the item's values are inside the run and the tile, which equal the level that is counted)
+        const uint32_t inmask = ((1u << (j1 < 0 ? 0 : j1)) - 1u) & ~((1u << j0) - 1u);
         uint32_t eq = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const bool in = j >= j0 && j < j1;
-          n_flag += in && (is_def ? (x[j] != cmp) : (x[j] == cmp));
-          eq |= (in && x[j] == cmp) ? 1u << j : 0u;
+          eq |= x[j] == cmp ? 1u << j : 0u;
           out4[j] = x[j];
         }
+        eq &= inmask;
+        n_flag += __builtin_popcount(is_def ? inmask ^ eq : eq);
         if (s_bits && is_def && j1 > j0) {
           // the item's slots that hold a value, at their places in the tile's bitmap
           const uint32_t b0 = (uint32_t)(vrel + j0), mm = eq >> j0, sh = b0 & 31u;

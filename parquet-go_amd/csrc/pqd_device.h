@@ -38,12 +38,27 @@ __device__ __forceinline__ void unpack8(const uint32_t *s_stage, uint32_t rel, u
   }
 }
 
-// Stores values j0 .. j1-1 of an item (eight output elements starting at `outp`).
+// Stores values j0 .. j1-1 of an item (eight output elements starting at `outp`).  An item that starts with its first
+// value - all but a tile's first - goes out as whole vectors and at most three single elements, whatever its length: the
+// lanes of a wavefront hold items of all lengths, and every form of store that any of them needs is issued for all.
 __device__ __forceinline__ void store_item(uint32_t *outp, const uint32_t y[8], int j0, int j1) {
-  if (j0 == 0 && j1 == 8) {
-    U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}}, o1 = {{y[4], y[5], y[6], y[7]}};
-    reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0;
-    reinterpret_cast<U32x4Unaligned *>(outp)[1] = o1;
+  if (j0 == 0) {
+    if (j1 >= 4) {
+      U32x4Unaligned o0 = {{y[0], y[1], y[2], y[3]}};
+      reinterpret_cast<U32x4Unaligned *>(outp)[0] = o0;
+    }
+    if (j1 >= 8) {
+      U32x4Unaligned o1 = {{y[4], y[5], y[6], y[7]}};
+      reinterpret_cast<U32x4Unaligned *>(outp)[1] = o1;
+    } else if (j1 > 0) {
+      const bool hi = j1 >= 4;
+      const int r = j1 & 3;
+      uint32_t *q = outp + (hi ? 4 : 0);
+      const uint32_t s0 = hi ? y[4] : y[0], s1 = hi ? y[5] : y[1], s2 = hi ? y[6] : y[2];
+      if (r > 0) q[0] = s0;
+      if (r > 1) q[1] = s1;
+      if (r > 2) q[2] = s2;
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 8; j++)
