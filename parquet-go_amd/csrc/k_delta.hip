@@ -868,17 +868,26 @@ __device__ __forceinline__ T delta_block_sum(const uint32_t *win, uint32_t r, ui
 
 // One wavefront per unit of 32 blocks: stage the packed bytes in LDS, add up every block's deltas, publish the unit's
 // total, collect the totals of the units before it in the page, decode two blocks per step.
-template <class T>
-__global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
+// Two wavefronts share a unit: its window, its table entries and its block sums sit in LDS once, and each wavefront takes
+// half of the steps of both sweeps.  What bounds the kernel is how many wavefronts the LDS windows leave room for (a unit's
+// first trip to memory, the wait for the totals in front of it and its stores are covered by other wavefronts only), and
+// this way a window keeps two in flight.  Everything that is not a sweep - the record, the entries, the scan of the block
+// sums, the look-back - is done by both alike (they read the same words); only the first one publishes.
+// (Measured on 512 Mi values of w = 12: INT32 0.78 -> 0.70 ms; INT64, whose stores are twice the bytes, 1.17 -> 1.21 ms - it
+//  keeps one wavefront per unit.)
+template <class T, int kUnitThreads>
+__global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
   extern __shared__ uint4 win4[];           // w.win_bytes + kWinSlack
   __shared__ DeltaBlock s_ent[kMaxUnitBlocks];
   __shared__ uint64_t s_prev[kMaxUnitBlocks];
   __shared__ uint32_t s_tot[kMaxUnitBlocks];
   const uint32_t kUnitBlocks = 1u << w.ushift;
   const uint32_t kWinBytes = (uint32_t)w.win_bytes;
-  __shared__ uint4 s_stage[sizeof(T) == 8 ? 128 : 1];
+  __shared__ uint4 s_stage_all[sizeof(T) == 8 ? 2 * kUnitThreads : 1];
   uint32_t *win = reinterpret_cast<uint32_t *>(win4);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = kUnitThreads > 64 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+  uint4 *s_stage = s_stage_all + (sizeof(T) == 8 ? 128 * wv : 0);
   const int64_t u = blockIdx.x;
   // the unit's record: sixteen dwords, one load
   const uint32_t rv = reinterpret_cast<const uint32_t *>(w.units + u)[lane & 15];
@@ -894,7 +903,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   const int64_t lim = (int64_t)((c.in + c.in_len) - src);          // bytes of the buffer from src on
   const uint32_t src_al = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
   T *out = values_out + r64(10);
-  if (g == 0 && lane == 0) out[0] = first;
+  if (g == 0 && tid == 0) out[0] = first;
   const uint32_t b0 = kUnitBlocks * g;
   const uint32_t nb_here = b0 >= n_blocks ? 0u : (n_blocks - b0 < kUnitBlocks ? n_blocks - b0 : kUnitBlocks);
 
@@ -907,18 +916,18 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   const bool one_window = nb_here != 0u && win_end - win_a0 <= kWinBytes;
   auto fill_window = [&](uint32_t a0, uint32_t end) {
     // (a0 may lie up to 15 bytes in front of the stream: signed from here on)  All loads first, then the LDS writes.
-    constexpr int kSweeps = (kMaxWinBytes + 1023) / 1024;   // (sweeps past `end` load and write nothing)
-    const int64_t o0 = (int64_t)(int32_t)a0 + 16 * lane;
+    constexpr int kSweeps = (kMaxWinBytes + 16 * kUnitThreads - 1) / (16 * kUnitThreads);   // (sweeps past `end` load and write nothing)
+    const int64_t o0 = (int64_t)(int32_t)a0 + 16 * tid;
     uint4 x[kSweeps];
 #pragma unroll
     for (int i = 0; i < kSweeps; i++) {
-      const int64_t o = o0 + 1024 * i;
+      const int64_t o = o0 + 16 * kUnitThreads * i;
       x[i] = make_uint4(0u, 0u, 0u, 0u);
       if (o < (int64_t)end && o < lim) x[i] = *reinterpret_cast<const uint4 *>(src + o);   // (16-byte aligned; its granule holds bytes of the buffer)
     }
 #pragma unroll
     for (int i = 0; i < kSweeps; i++)
-      if (o0 + 1024 * i < (int64_t)end) win4[(uint32_t)(16 * lane + 1024 * i) >> 4] = x[i];
+      if (o0 + 16 * kUnitThreads * i < (int64_t)end) win4[(uint32_t)(16 * tid + 16 * kUnitThreads * i) >> 4] = x[i];
   };
   if (one_window) fill_window(win_a0, win_end);
   if (spec_len != 0u) {
@@ -945,7 +954,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
       E = DeltaBlock{h.data_off, h.widths, h.md};
     }
     if (__ballot(!ok) != 0ull) {
-      if (lane == 0) {
+      if (tid == 0) {
         __hip_atomic_store(&w.gsum[2 * u], 3ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&w.gsum[2 * u + 1], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.state[p].delta_fast = 2;
@@ -1011,10 +1020,14 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
     cs[3] = cs[2] + ((uint32_t)(lo2 >> wm) & mask);
   };
   T s = 0;
+  // the steps of this wavefront in the two sweeps: half of them each (units of eight blocks - four steps - are one wavefront's)
+  const int n_steps = (int)kUnitBlocks / 2;
+  const bool shared = kUnitThreads > 64 && n_steps >= 8;
+  const int step_lo = shared ? wv * (n_steps / 2) : 0, step_hi = shared ? step_lo + n_steps / 2 : (wv == 0 ? n_steps : 0);
   if (quick) {
     // (four steps at a time without a branch between them, so that the LDS reads of one step overlap the arithmetic
     //  of another; steps past the unit's last block unpack block 0 again and keep nothing)
-    for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
+    for (int i0 = step_lo; i0 < step_hi; i0 += 4) {
       if (2u * (uint32_t)i0 < nb_here) {
 #pragma unroll
         for (int i = i0; i < i0 + 4; i++) {
@@ -1039,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   }
   const T incl = wave_incl_scan(s, lane);
   const T total = bcast_lane(incl, 63);
-  if (lane == 0) {
+  if (tid == 0) {
     publish_word(&w.gsum[2 * u], (uint32_t)total);
     if (sizeof(T) == 8) publish_word(&w.gsum[2 * u + 1], (uint32_t)((uint64_t)total >> 32));
   }
@@ -1066,7 +1079,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   if (__ballot(late) != 0ull) {
     // a total never came (the units of a page did not start in order): the page is decoded again by the
     // wavefront-per-page kernel that runs after this one
-    if (lane == 0) c.state[p].delta_fast = 2;
+    if (tid == 0) c.state[p].delta_fast = 2;
     return;
   }
   if ((uint32_t)lane < kUnitBlocks) s_prev[lane] = (uint64_t)(T)(first + before + (T)(incl - s));
@@ -1074,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
 
   // ---- values ----
   if (quick) {
-    for (int i0 = 0; i0 < (int)kUnitBlocks / 2; i0 += 4) {
+    for (int i0 = step_lo; i0 < step_hi; i0 += 4) {
       if (2u * (uint32_t)i0 >= nb_here) break;
 #pragma unroll
       for (int i = i0; i < i0 + 4; i++) {
@@ -1124,7 +1137,7 @@ __global__ __launch_bounds__(64) void k_delta_units(ChunkCtx c, T *__restrict__ 
   if (!one_window) be = stage(0u);
   for (uint32_t bs = 0; bs < nb_here;) {
 #pragma unroll 1
-    for (uint32_t i = bs; i < be; i += 2u) {
+    for (uint32_t i = bs; i < be && wv == 0; i += 2u) {      // (the slow kinds of unit: one wavefront's work, the other one helps to stage)
       const uint32_t blk_l = i + (uint32_t)half;
       const bool live = blk_l < be;
       const DeltaBlock e = s_ent[live ? blk_l : i];
@@ -1210,8 +1223,8 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
     const dim3 grid((unsigned)w.n_units);
     const size_t shmem = (size_t)win_bytes + kWinSlack;
-    if (elem_size == 4) hipLaunchKernelGGL(k_delta_units<uint32_t>, grid, dim3(64), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
-    else hipLaunchKernelGGL(k_delta_units<uint64_t>, grid, dim3(64), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
+    if (elem_size == 4) hipLaunchKernelGGL((k_delta_units<uint32_t, 128>), grid, dim3(128), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
+    else hipLaunchKernelGGL((k_delta_units<uint64_t, 64>), grid, dim3(64), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
   }
   if (elem_size == 4)
     hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel, narrow ? 1 : 0);
