@@ -868,19 +868,21 @@ __device__ __forceinline__ T delta_block_sum(const uint32_t *win, uint32_t r, ui
 
 // One wavefront per unit of 32 blocks: stage the packed bytes in LDS, add up every block's deltas, publish the unit's
 // total, collect the totals of the units before it in the page, decode two blocks per step.
-// Two wavefronts share a unit: its window, its table entries and its block sums sit in LDS once, and each wavefront takes
-// half of the steps of both sweeps.  What bounds the kernel is how many wavefronts the LDS windows leave room for (a unit's
-// first trip to memory, the wait for the totals in front of it and its stores are covered by other wavefronts only), and
-// this way a window keeps two in flight.  Everything that is not a sweep - the record, the entries, the scan of the block
-// sums, the look-back - is done by both alike (they read the same words); only the first one publishes.
-// (Measured on 512 Mi values of w = 12: INT32 0.78 -> 0.70 ms; INT64, whose stores are twice the bytes, 1.17 -> 1.21 ms - it
-//  keeps one wavefront per unit.)
+// Several wavefronts share a unit: its window, its table entries and its block sums sit in LDS once, and each wavefront
+// takes its share of the steps of both sweeps.  What bounds the kernel is how many wavefronts the LDS windows leave room
+// for (a unit's first trip to memory, the wait for the totals in front of it and its stores are covered by other
+// wavefronts only), and this way a window keeps several in flight.  The record, the entries and the scan of the block sums
+// are done by all alike (they read the same words); the first wavefront alone publishes the unit's total and looks back
+// for the totals in front of it (with every wavefront polling, two per unit were no gain for INT64 and 10 % for INT32).
+// Measured on 512 Mi values of w = 12, kernels: INT32 0.78 ms with one wavefront per unit, 0.67 with two, 0.64 with four,
+// 0.82 with eight; INT64 1.16 / 1.12 / 1.14.
 template <class T, int kUnitThreads>
 __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
   extern __shared__ uint4 win4[];           // w.win_bytes + kWinSlack
   __shared__ DeltaBlock s_ent[kMaxUnitBlocks];
   __shared__ uint64_t s_prev[kMaxUnitBlocks];
   __shared__ uint32_t s_tot[kMaxUnitBlocks];
+  __shared__ int s_late;
   const uint32_t kUnitBlocks = 1u << w.ushift;
   const uint32_t kWinBytes = (uint32_t)w.win_bytes;
   __shared__ uint4 s_stage_all[sizeof(T) == 8 ? 2 * kUnitThreads : 1];
@@ -1022,8 +1024,9 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
   T s = 0;
   // the steps of this wavefront in the two sweeps: half of them each (units of eight blocks - four steps - are one wavefront's)
   const int n_steps = (int)kUnitBlocks / 2;
-  const bool shared = kUnitThreads > 64 && n_steps >= 8;
-  const int step_lo = shared ? wv * (n_steps / 2) : 0, step_hi = shared ? step_lo + n_steps / 2 : (wv == 0 ? n_steps : 0);
+  constexpr int kNW = kUnitThreads / 64;
+  const bool shared = kNW > 1 && n_steps >= 4 * kNW;
+  const int step_lo = shared ? wv * (n_steps / kNW) : 0, step_hi = shared ? step_lo + n_steps / kNW : (wv == 0 ? n_steps : 0);
   if (quick) {
     // (four steps at a time without a branch between them, so that the LDS reads of one step overlap the arithmetic
     //  of another; steps past the unit's last block unpack block 0 again and keep nothing)
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
   // the units before this one in the page: they started no later than this one and publish before they wait
   T before = 0;
   bool late = false;
-  for (uint32_t j0 = 0; j0 < g; j0 += 64u) {
+  for (uint32_t j0 = 0; j0 < g && wv == 0; j0 += 64u) {      // (the first wavefront looks back for both)
     const uint32_t j = j0 + (uint32_t)lane;
     T v = 0;
     if (j < g) {
@@ -1076,14 +1079,18 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
     }
     before += bcast_lane(wave_incl_scan(v, lane), 63);
   }
-  if (__ballot(late) != 0ull) {
+  if (wv == 0) {
+    const bool any_late = __ballot(late) != 0ull;
+    if (lane == 0) s_late = any_late ? 1 : 0;
+    if ((uint32_t)lane < kUnitBlocks) s_prev[lane] = (uint64_t)(T)(first + before + (T)(incl - s));
+  }
+  __syncthreads();
+  if (s_late) {
     // a total never came (the units of a page did not start in order): the page is decoded again by the
     // wavefront-per-page kernel that runs after this one
     if (tid == 0) c.state[p].delta_fast = 2;
     return;
   }
-  if ((uint32_t)lane < kUnitBlocks) s_prev[lane] = (uint64_t)(T)(first + before + (T)(incl - s));
-  __syncthreads();
 
   // ---- values ----
   if (quick) {
@@ -1223,8 +1230,8 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     hipLaunchKernelGGL(k_delta_blocks, dim3(c.nd), dim3(64), 0, stream, c, encoding, src_sel, w);
     const dim3 grid((unsigned)w.n_units);
     const size_t shmem = (size_t)win_bytes + kWinSlack;
-    if (elem_size == 4) hipLaunchKernelGGL((k_delta_units<uint32_t, 128>), grid, dim3(128), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
-    else hipLaunchKernelGGL((k_delta_units<uint64_t, 64>), grid, dim3(64), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
+    if (elem_size == 4) hipLaunchKernelGGL((k_delta_units<uint32_t, 256>), grid, dim3(256), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
+    else hipLaunchKernelGGL((k_delta_units<uint64_t, 128>), grid, dim3(128), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
   }
   if (elem_size == 4)
     hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel, narrow ? 1 : 0);
