@@ -1043,21 +1043,25 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
       }
     }
     __syncthreads();
-    if ((uint32_t)lane < nb_here && b0 + (uint32_t)lane + 1u < n_blocks)   // (the last block's sum is nobody's start)
+    if (wv == 0 && (uint32_t)lane < nb_here && b0 + (uint32_t)lane + 1u < n_blocks)   // (the last block's sum is nobody's start)
       s = (T)s_tot[lane] + (T)128 * DeltaTraits<T>::zigzag(E.min_delta);
   } else {
     for (uint32_t bs = 0; bs < nb_here;) {
-      if ((uint32_t)lane >= bs && (uint32_t)lane < be && b0 + (uint32_t)lane + 1u < n_blocks)
+      if (wv == 0 && (uint32_t)lane >= bs && (uint32_t)lane < be && b0 + (uint32_t)lane + 1u < n_blocks)
         s = delta_block_sum<T>(win, E.data_off - win_a0, E.widths) + (T)128 * DeltaTraits<T>::zigzag(E.min_delta);
       bs = be;
       if (bs < nb_here) be = stage(bs);
     }
   }
-  const T incl = wave_incl_scan(s, lane);
-  const T total = bcast_lane(incl, 63);
-  if (tid == 0) {
-    publish_word(&w.gsum[2 * u], (uint32_t)total);
-    if (sizeof(T) == 8) publish_word(&w.gsum[2 * u + 1], (uint32_t)((uint64_t)total >> 32));
+  // (the block sums, their scan, the unit's total and the look-back are the first wavefront's alone)
+  T incl = 0;
+  if (wv == 0) {
+    incl = wave_incl_scan(s, lane);
+    const T total = bcast_lane(incl, 63);
+    if (lane == 0) {
+      publish_word(&w.gsum[2 * u], (uint32_t)total);
+      if (sizeof(T) == 8) publish_word(&w.gsum[2 * u + 1], (uint32_t)((uint64_t)total >> 32));
+    }
   }
   if (nb_here == 0u) return;
   // the units before this one in the page: they started no later than this one and publish before they wait
