@@ -874,8 +874,8 @@ __device__ __forceinline__ T delta_block_sum(const uint32_t *win, uint32_t r, ui
 // wavefronts only), and this way a window keeps several in flight.  The record, the entries and the scan of the block sums
 // are done by all alike (they read the same words); the first wavefront alone publishes the unit's total and looks back
 // for the totals in front of it (with every wavefront polling, two per unit were no gain for INT64 and 10 % for INT32).
-// Measured on 512 Mi values of w = 12, kernels: INT32 0.78 ms with one wavefront per unit, 0.67 with two, 0.64 with four,
-// 0.82 with eight; INT64 1.16 / 1.12 / 1.14.
+// Measured on 512 Mi values of w = 12, kernels (wavefronts per unit 1 / 2 / 4 / 8): INT32 0.78 / 0.67 / 0.61 / 0.82 ms,
+// INT64 1.16 / 1.12 / 1.05 ms.
 template <class T, int kUnitThreads>
 __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__restrict__ values_out, DeltaWork w) {
   extern __shared__ uint4 win4[];           // w.win_bytes + kWinSlack
@@ -1235,7 +1235,7 @@ hipError_t launch_delta_decode(const ChunkCtx &c, uint8_t *values_out, int elem_
     const dim3 grid((unsigned)w.n_units);
     const size_t shmem = (size_t)win_bytes + kWinSlack;
     if (elem_size == 4) hipLaunchKernelGGL((k_delta_units<uint32_t, 256>), grid, dim3(256), shmem, stream, c, reinterpret_cast<uint32_t *>(values_out), w);
-    else hipLaunchKernelGGL((k_delta_units<uint64_t, 128>), grid, dim3(128), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
+    else hipLaunchKernelGGL((k_delta_units<uint64_t, 256>), grid, dim3(256), shmem, stream, c, reinterpret_cast<uint64_t *>(values_out), w);
   }
   if (elem_size == 4)
     hipLaunchKernelGGL(k_delta_decode<uint32_t>, dim3(c.nd), dim3(64), 0, stream, c, reinterpret_cast<uint32_t *>(values_out), encoding, src_sel, narrow ? 1 : 0);
