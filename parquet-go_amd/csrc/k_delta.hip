@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
   __shared__ DeltaBlock s_ent[kMaxUnitBlocks];
   __shared__ uint64_t s_prev[kMaxUnitBlocks];
   __shared__ uint32_t s_tot[kMaxUnitBlocks];
-  __shared__ int s_late;
+  __shared__ int s_late, s_fail;
   const uint32_t kUnitBlocks = 1u << w.ushift;
   const uint32_t kWinBytes = (uint32_t)w.win_bytes;
   __shared__ uint4 s_stage_all[sizeof(T) == 8 ? 2 * kUnitThreads : 1];
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
 
   // one block per lane (of the first 32)
   DeltaBlock E{0u, 0u, 0ull};
-  if ((uint32_t)lane < nb_here && spec_len == 0u) E = tb[b0 + (uint32_t)lane];
+  if (wv == 0 && (uint32_t)lane < nb_here && spec_len == 0u) E = tb[b0 + (uint32_t)lane];      // (the first wavefront reads or works out the entries; the others take them from LDS)
   // The unit's bytes, when the window holds them all, are asked for at once with the table entries (the record
   // names the range); otherwise the window moves over the blocks.
   uint32_t win_a0 = win_start - ((src_al + win_start) & 15u);
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
     const uint64_t n_values = (uint64_t)tbase >> 32;
     bool ok = one_window;
     __syncthreads();
-    if (ok && (uint32_t)lane < nb_here) {
+    if (wv == 0 && ok && (uint32_t)lane < nb_here) {
       const uint32_t pj = win_start + (uint32_t)lane * spec_len;
       const uint32_t r = pj - win_a0;
       const uint32_t *q = win + (r >> 2);
@@ -955,19 +955,22 @@ __global__ __launch_bounds__(kUnitThreads) void k_delta_units(ChunkCtx c, T *__r
       if (w.narrow && ok && !delta_narrow_ok(h.md, h.widths)) c.chunk_status[kLayoutMismatch] = 1;
       E = DeltaBlock{h.data_off, h.widths, h.md};
     }
-    if (__ballot(!ok) != 0ull) {
-      if (tid == 0) {
+    if (wv == 0 && lane == 0) s_fail = 0;
+    if (wv == 0 && __ballot(!ok) != 0ull) {
+      if (lane == 0) {
         __hip_atomic_store(&w.gsum[2 * u], 3ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&w.gsum[2 * u + 1], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.state[p].delta_fast = 2;
+        s_fail = 1;
       }
-      return;
     }
   }
+  if (wv == 0 && (uint32_t)lane < kUnitBlocks) s_ent[lane] = E;
+  __syncthreads();
+  if (spec_len != 0u && s_fail) return;      // (uniform) a block of another length: the page is decoded again
+  if (wv != 0 && (uint32_t)lane < kUnitBlocks) E = s_ent[lane];
   const uint32_t wsum = (E.widths & 0xFFu) + ((E.widths >> 8) & 0xFFu) + ((E.widths >> 16) & 0xFFu) + (E.widths >> 24);
   const uint32_t data_end = E.data_off + 4u * wsum;
-  if ((uint32_t)lane < kUnitBlocks) s_ent[lane] = E;
-  __syncthreads();
 
   // Stage the bytes of blocks [bs, be) - as many as the window holds - and return be.  The window starts at the
   // 16-byte boundary at or below the first block; every block has its bytes inside the stream (k_delta_blocks).
