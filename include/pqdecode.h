@@ -129,7 +129,7 @@ int pqd_set_profiling(pqd_handle *h, int on);
 
 /* Kernel-variant choices of a handle.  Results never depend on them; tests pin each variant with them.  value -1
  * returns a choice to the library.  New handles start from the environment (read once per process):
- * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_DELTA_BLOCKS=0|1, PQD_FUSED=0|1. */
+ * PQD_PRESCAN=wide|wave, PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_DELTA_BLOCKS=0|1, PQD_FUSED=0|1, PQD_BYTE_OFFSETS=0|1, PQD_DEVICE_TABLES=0|1. */
 enum {
   PQD_OPT_PRESCAN = 0,        /* run-header walk: 0 a wavefront per stream, 1 a workgroup per stream */
   PQD_OPT_DIRECT_RLE = 1,     /* 0 / 1: expansion of RLE-only pages straight from the page */
@@ -143,7 +143,9 @@ enum {
   PQD_OPT_FUSED = 7,          /* 0 / 1: index streams of large pages walked and expanded by one workgroup per page, in one pass */
   PQD_OPT_BYTE_OFFSETS = 8,   /* 0 / 1: BYTE_ARRAY output offsets in one pass over the lengths (tiles look back for the sum in front of them), and for
                                  chunks of DELTA_LENGTH_BYTE_ARRAY pages only straight from the decoded lengths; 0: sums, scan and offsets as three kernels */
-  PQD_OPT_COUNT = 9
+  PQD_OPT_DEVICE_TABLES = 9,  /* 0 / 1: per-stream tables of a call (run-table ranges, tile prefixes, tile -> stream maps) worked out by a kernel from
+                                 the uploaded page table instead of by the host; the library's choice: chunks of 4096 data pages and more */
+  PQD_OPT_COUNT = 10
 };
 int pqd_set_option(pqd_handle *h, int option, int value);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "pqd_decode_chunk_device_noalloc", "pqd_direct_streams",
 ]
 
-OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON, OPT_DELTA_BLOCKS, OPT_FUSED, OPT_BYTE_OFFSETS = range(9)
+OPT_PRESCAN, OPT_DIRECT_RLE, OPT_JUMP, OPT_PLAIN_SCATTER, OPT_SPLIT, OPT_POISON, OPT_DELTA_BLOCKS, OPT_FUSED, OPT_BYTE_OFFSETS, OPT_DEVICE_TABLES = range(10)
 LEVELS_ONLY = 1
 ERR_CAPACITY = -14
 

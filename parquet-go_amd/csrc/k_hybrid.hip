@@ -120,6 +120,163 @@ __global__ void k_page_setup(ChunkCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stream_tables: what the host otherwise writes per page and uploads - the three stream seeds of every data page,
+// the tile prefixes of the level, index and plain expansions and the two tile -> stream maps - worked out from the
+// uploaded page table by one workgroup: a running sum over the pages of the run-table room and the tiles each takes.
+// For chunks of very many small pages (the reference's writer cuts pages at 8 KiB, writer/writer.go:63-65) the host's
+// pass over the pages and the upload of its tables cost more than the kernels that decode the chunk.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTablesThreads = 256;
+constexpr int kTablesPer = 4;      // consecutive pages per thread
+constexpr int kTablesPages = kTablesThreads * kTablesPer;   // pages per workgroup
+
+struct TableAdds {
+  int64_t x[4];      // what a page adds to: run room, tiles, run room of the pages whose values are an index stream, and - in one word, both
+                     // fit 32 bits with their totals (the host has checked them) - tiles of those pages << 32 | plain tiles
+  int64_t tiles, rcap;
+  int d;
+  bool want;
+};
+
+__device__ __forceinline__ TableAdds table_adds(const ChunkCtx &c, const TableBases &b, int64_t p) {
+  TableAdds a;
+  a.d = -1;
+  int e = 0;
+  int64_t nv = 0, body_len = 0;
+  if (p < c.n_pages) {
+    const PageIn &pi = c.pages[p];
+    a.d = pi.data_idx; e = pi.encoding; nv = pi.num_values > 0 ? pi.num_values : 0; body_len = pi.body_len;
+  }
+  const bool data = a.d >= 0;
+  a.tiles = data ? (nv + kTile - 1) / kTile : 0;
+  a.rcap = data ? (nv < body_len ? nv : body_len) + 2 : 0;
+  a.want = data && b.wanted[2] && (e == PQD_ENC_PLAIN_DICTIONARY || e == PQD_ENC_RLE_DICTIONARY || (e == PQD_ENC_RLE && b.rle_typed));
+  int64_t plain_tiles = 0;
+  if (data && b.wanted[2] && (e == PQD_ENC_PLAIN || (e == PQD_ENC_BYTE_STREAM_SPLIT && b.is_real))) {
+    const int64_t units = c.physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)c.elem_size;
+    plain_tiles = (units + kPlainTile - 1) / kPlainTile;
+  }
+  a.x[0] = a.rcap; a.x[1] = a.tiles; a.x[2] = a.want ? a.rcap : 0; a.x[3] = ((a.want ? a.tiles : 0) << 32) | plain_tiles;
+  return a;
+}
+
+// the four sums over the workgroup's threads, in every thread
+__device__ __forceinline__ void tables_block_sum(int64_t (&v)[4], int64_t (*s_part)[4]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    if (lane == 0) s_part[wv][k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int64_t t = 0;
+    for (int j = 0; j < kTablesThreads / 64; j++) t += s_part[j][k];
+    v[k] = t;
+  }
+  __syncthreads();
+}
+
+// first the sums of every kTablesPages pages ...
+__global__ __launch_bounds__(kTablesThreads) void k_stream_table_sums(ChunkCtx c, TableBases b, int64_t *sums) {
+  __shared__ int64_t s_part[kTablesThreads / 64][4];
+  int64_t mine[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < kTablesPer; i++) {
+    const TableAdds a = table_adds(c, b, (int64_t)blockIdx.x * kTablesPages + (int64_t)threadIdx.x * kTablesPer + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine[k] += a.x[k];
+  }
+  tables_block_sum(mine, s_part);
+  if (threadIdx.x < 4) sums[4 * (size_t)blockIdx.x + threadIdx.x] = mine[threadIdx.x];
+}
+
+// ... then the tables: a workgroup adds up the sums in front of its pages and numbers its own pages from there
+__global__ __launch_bounds__(kTablesThreads) void k_stream_tables(ChunkCtx c, TableBases b, const int64_t *sums, StreamSeed *seeds, int32_t *tp_levels,
+                                                                  int32_t *tp_dict, int32_t *tp_plain, int32_t *ts_levels, int32_t *ts_dict) {
+  __shared__ int64_t s_part[kTablesThreads / 64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nd = c.nd;
+  int64_t before[4] = {0, 0, 0, 0};
+  for (int j = tid; j < (int)blockIdx.x; j += kTablesThreads) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) before[k] += sums[4 * (size_t)j + k];
+  }
+  tables_block_sum(before, s_part);
+  TableAdds a[kTablesPer];
+  int64_t mine[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < kTablesPer; i++) {
+    a[i] = table_adds(c, b, (int64_t)blockIdx.x * kTablesPages + (int64_t)tid * kTablesPer + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine[k] += a[i].x[k];
+  }
+  int64_t ex[4];       // the sums in front of this thread's first page
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int64_t v = mine[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t up = __shfl_up(v, o, 64);
+      if (lane >= o) v += up;
+    }
+    ex[k] = v - mine[k];
+    if (lane == 63) s_part[wv][k] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int64_t t = before[k];
+    for (int j = 0; j < wv; j++) t += s_part[j][k];
+    ex[k] += t;
+  }
+#pragma unroll
+  for (int i = 0; i < kTablesPer; i++) {
+    if (a[i].d >= 0) {
+      const int dd = a[i].d;
+      const int64_t tiles = a[i].tiles, rcap = a[i].rcap;
+      const int64_t acc_runs = ex[0], acc_tiles = ex[1], v_runs = ex[2], v_tiles = ex[3] >> 32, t_pl = ex[3] & 0xFFFFFFFFll;
+      for (int g = 0; g < 2; g++) {
+        StreamSeed sd;
+        int32_t tp;
+        if (b.wanted[g]) {
+          sd.run_base = b.run_base[g] + acc_runs; sd.run_cap = (int32_t)rcap; sd.tile_base = (int32_t)(b.tile_base[g] + acc_tiles + dd);
+          tp = (int32_t)(b.tlv_base[g] + acc_tiles);
+          for (int64_t t = 0; t < tiles; t++) ts_levels[tp + t] = g * nd + dd;
+        } else {
+          sd.run_base = b.run_base[g]; sd.run_cap = 0; sd.tile_base = (int32_t)(b.tile_base[g] + dd);
+          tp = (int32_t)b.tlv_base[g];
+        }
+        seeds[(size_t)g * nd + dd] = sd;
+        tp_levels[(size_t)g * nd + dd] = tp;
+      }
+      StreamSeed sv;
+      if (b.wanted[2]) {
+        sv.run_base = b.run_base[2] + v_runs; sv.run_cap = (int32_t)(a[i].want ? rcap : 0); sv.tile_base = (int32_t)(b.tile_base[2] + v_tiles + dd);
+        tp_dict[dd] = (int32_t)v_tiles;
+        tp_plain[dd] = (int32_t)t_pl;
+        if (a[i].want) for (int64_t t = 0; t < tiles; t++) ts_dict[v_tiles + t] = dd;
+      } else {
+        sv.run_base = b.run_base[2]; sv.run_cap = 0; sv.tile_base = (int32_t)(b.tile_base[2] + dd);
+        tp_dict[dd] = 0; tp_plain[dd] = 0;
+      }
+      seeds[(size_t)2 * nd + dd] = sv;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) ex[k] += a[i].x[k];
+  }
+  // the end entries: by the thread that holds the chunk's last page (after it, ex holds the sums over all pages)
+  if (blockIdx.x == gridDim.x - 1 && tid == kTablesThreads - 1) {
+    const int64_t acc_tiles = ex[1];
+    tp_levels[2 * (size_t)nd] = (int32_t)((b.wanted[0] ? acc_tiles : 0) + (b.wanted[1] ? acc_tiles : 0));
+    tp_dict[nd] = b.wanted[2] ? (int32_t)(ex[3] >> 32) : 0;
+    tp_plain[nd] = b.wanted[2] ? (int32_t)(ex[3] & 0xFFFFFFFFll) : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_hybrid_prescan: one wavefront per stream walks the varint run headers (the part of
 // ReadRLEBitPackedHybrid that is inherently serial) and writes the run table, the tile -> run
 // index and the stream totals.  The stream is staged through LDS in 4 KiB windows loaded with
@@ -1051,6 +1208,18 @@ __global__ __launch_bounds__(256) void k_collect_status(ChunkCtx c, int32_t *out
 hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream) {
   if (c.n_pages <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_page_setup, dim3((c.n_pages + 255) / 256), dim3(256), 0, stream, c);
+  return hipGetLastError();
+}
+
+size_t stream_tables_work_bytes(int n_pages) { return 32 * ((size_t)(n_pages > 0 ? n_pages : 0) / kTablesPages + 2); }
+
+hipError_t launch_stream_tables(const ChunkCtx &c, const TableBases &b, void *work, StreamSeed *seeds, int32_t *tp_levels, int32_t *tp_dict, int32_t *tp_plain,
+                                int32_t *ts_levels, int32_t *ts_dict, hipStream_t stream) {
+  if (c.n_pages <= 0) return hipSuccess;
+  const int nb = (c.n_pages + kTablesPages - 1) / kTablesPages;
+  int64_t *sums = static_cast<int64_t *>(work);
+  hipLaunchKernelGGL(k_stream_table_sums, dim3(nb), dim3(kTablesThreads), 0, stream, c, b, sums);
+  hipLaunchKernelGGL(k_stream_tables, dim3(nb), dim3(kTablesThreads), 0, stream, c, b, sums, seeds, tp_levels, tp_dict, tp_plain, ts_levels, ts_dict);
   return hipGetLastError();
 }
 

@@ -136,7 +136,7 @@ struct KernelEvent {
 };
 
 // Process-wide defaults of the per-handle options, read from the environment once (PQD_PRESCAN=wide|wave,
-// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_FUSED=0|1, PQD_BYTE_OFFSETS=0|1, PQD_HEAVY_LANES=0..4).
+// PQD_DIRECT_RLE=0|1, PQD_JUMP=0|1, PQD_NO_PLAIN_SCATTER, PQD_SPLIT=0|1, PQD_POISON=1, PQD_FUSED=0|1, PQD_BYTE_OFFSETS=0|1, PQD_DEVICE_TABLES=0|1, PQD_HEAVY_LANES=0..4).
 struct Defaults {
   int opt[PQD_OPT_COUNT];
   int heavy_lanes;
@@ -156,6 +156,7 @@ const Defaults &defaults() {
     if (const char *e = std::getenv("PQD_DELTA_BLOCKS")) x.opt[PQD_OPT_DELTA_BLOCKS] = e[0] - '0';
     if (const char *e = std::getenv("PQD_FUSED")) x.opt[PQD_OPT_FUSED] = e[0] == '1';
     if (const char *e = std::getenv("PQD_BYTE_OFFSETS")) x.opt[PQD_OPT_BYTE_OFFSETS] = e[0] == '1';
+    if (const char *e = std::getenv("PQD_DEVICE_TABLES")) x.opt[PQD_OPT_DEVICE_TABLES] = e[0] == '1';
     const char *e = std::getenv("PQD_HEAVY_LANES");
     const int v = e ? std::atoi(e) : 0;
     x.heavy_lanes = v < 0 ? 0 : (v > kMaxLanes ? kMaxLanes : v);
@@ -187,6 +188,8 @@ struct pqd_handle {
   // description of the last decode call
   HostSpan<PageIn> h_pages;        // inside stage_meta: valid until the handle's next call
   std::vector<int32_t> h_dict_pages;
+  struct DictGroup { int dict_of, first_page; int64_t tiles; };      // a run of data pages under one dictionary (or none): its index tiles
+  std::vector<DictGroup> h_dict_groups;
   pqd_column_desc col{};
   int n_pages = 0, nd = 0;
   int64_t total_slots = 0;
@@ -367,8 +370,12 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   if ((rc = h->stage_meta.ensure(pages_bytes + 256))) return rc;
   h->h_pages = HostSpan<PageIn>{static_cast<PageIn *>(h->stage_meta.p), (size_t)n_pages};
   h->h_dict_pages.clear();
+  h->h_dict_groups.clear();
+  double index_bpv = 0.0;      // most page bytes per value among the pages whose values are (or may be) an index stream
+  int max_dict_n = 0;
   int nd = 0;
   int64_t slots = 0, dict_total = 0, data_bytes = 0, all_bytes = 0, lv_runs = 0, lv_tiles = 0, max_page_bytes = 0;
+  int64_t ix_runs = 0, ix_tiles = 0, plain_tiles = 0;      // run room and tiles of the pages whose values are an index stream; tiles of the flat copies
   int host_status = PQD_OK, host_bad = -1;
   bool any_dict_enc = false, any_plain = false, any_delta = false, any_bss = false, any_rle = false;
   bool any_dlba = false, any_dba = false;
@@ -396,6 +403,20 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
           const int64_t nv = d.num_values > 0 ? d.num_values : 0;
           lv_runs += std::min<int64_t>(nv, d.length) + 2;
           lv_tiles += (nv + kTile - 1) / kTile;
+          if (is_dict_enc(d.encoding) || d.encoding == PQD_ENC_RLE)
+            index_bpv = std::max(index_bpv, d.num_values >= kTile ? (double)d.length / (double)d.num_values : 4.25);
+          if (!levels_only) {
+            if (h->h_dict_groups.empty() || h->h_dict_groups.back().dict_of != cur_dict) h->h_dict_groups.push_back({cur_dict, p, 0});
+            if (is_dict_enc(d.encoding) || (d.encoding == PQD_ENC_RLE && rle_typed && !is_bytes)) {
+              ix_runs += std::min<int64_t>(nv, d.length) + 2;
+              ix_tiles += (nv + kTile - 1) / kTile;
+              h->h_dict_groups.back().tiles += (nv + kTile - 1) / kTile;
+            }
+            if (d.encoding == PQD_ENC_PLAIN || (d.encoding == PQD_ENC_BYTE_STREAM_SPLIT && is_real)) {
+              const int64_t units = col->physical_type == PQD_BOOLEAN ? nv : nv * (int64_t)esz;
+              plain_tiles += (units + kPlainTile - 1) / kPlainTile;
+            }
+          }
         }
         if (cur_dict >= 0) {
           const PageIn &dp = h->h_pages[(size_t)cur_dict];
@@ -416,6 +437,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       } else if (d.page_type == PQD_DICTIONARY_PAGE) {
         pi.dict_page = p; pi.dict_n = d.num_values > 0 ? d.num_values : 0; pi.dict_off = dict_total;
         dict_total += pi.dict_n;
+        max_dict_n = std::max(max_dict_n, pi.dict_n);
         cur_dict = p;
         h->h_dict_pages.push_back(p);
       } else {
@@ -452,10 +474,16 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // definition levels, values), one pass over the pages: the level groups take the same room each (added up with the
   // page table), so every group's base is known beforehand.  A group no stream of which is decoded has empty run
   // ranges and one (end) entry per stream in the tile table.
+  // Chunks of very many pages leave that pass, the tile -> stream maps and their upload to a kernel (k_stream_tables):
+  // the totals the host needs for its buffers were added up with the page table.
+  bool device_tables = nd >= 4096;
+  if (h->opt[PQD_OPT_DEVICE_TABLES] >= 0) device_tables = h->opt[PQD_OPT_DEVICE_TABLES] == 1;
   int64_t run_total = 0, tile_total = 0;
+  TableBases tbases{};
+  int32_t n_lv_tiles = 0, n_lv_tiles_rep = 0, n_dc_tiles = 0, n_pl_tiles = 0;   // level tiles (all; those of the repetition levels), index tiles, plain tiles
   {
     const bool wanted[3] = {col->max_rep > 0, col->max_def > 0, !levels_only};
-    int64_t run_base[3], tile_base[3], tlv_base[2];
+    int64_t (&run_base)[3] = tbases.run_base, (&tile_base)[3] = tbases.tile_base, (&tlv_base)[2] = tbases.tlv_base;
     int64_t t_lv = 0;
     for (int g = 0; g < 2; g++) {
       run_base[g] = run_total; tile_base[g] = tile_total; tlv_base[g] = t_lv;
@@ -464,10 +492,15 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       t_lv += wanted[g] ? lv_tiles : 0;
     }
     run_base[2] = run_total; tile_base[2] = tile_total;
+    for (int g = 0; g < 3; g++) tbases.wanted[g] = wanted[g];
+    tbases.rle_typed = rle_typed && !is_bytes; tbases.is_real = is_real;
     if (tile_total > 0x7FFFFFF0ll || t_lv > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
+    if (tile_total + ix_tiles + nd > 0x7FFFFFF0ll || plain_tiles > 0x7FFFFFF0ll) return fail_arg("chunk too large (tiles)");
+    n_lv_tiles = (int32_t)t_lv; n_lv_tiles_rep = (int32_t)tlv_base[1];
+    n_dc_tiles = (int32_t)ix_tiles; n_pl_tiles = (int32_t)plain_tiles;
     int64_t acc_runs = 0, acc_tiles = 0, v_runs = 0, v_tiles = 0, t_dc = 0, t_pl = 0;
     StreamSeed *s0 = h_seeds.data(), *s1 = s0 + nd, *s2 = s1 + nd;
-    for (int p = 0; p < n_pages; p++) {
+    for (int p = 0; p < n_pages && !device_tables; p++) {
       const PageIn &pi = h->h_pages[(size_t)p];
       if (pi.data_idx < 0) continue;
       const int d = pi.data_idx;
@@ -501,21 +534,25 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
         tp_dict[(size_t)d] = 0; tp_plain[(size_t)d] = 0;
       }
     }
-    run_total += v_runs;
-    tile_total += v_tiles + nd;
+    run_total += wanted[2] ? ix_runs : 0;
+    tile_total += (wanted[2] ? ix_tiles : 0) + nd;
     if (tile_total > 0x7FFFFFF0ll) return fail_arg("chunk too large (tile table)");
-    tp_levels[2 * (size_t)nd] = (int32_t)t_lv;
-    tp_dict[(size_t)nd] = (int32_t)t_dc;
-    tp_plain[(size_t)nd] = (int32_t)t_pl;
+    if (!device_tables) {
+      tp_levels[2 * (size_t)nd] = (int32_t)t_lv;
+      tp_dict[(size_t)nd] = (int32_t)t_dc;
+      tp_plain[(size_t)nd] = (int32_t)t_pl;
+      if (v_runs != (wanted[2] ? ix_runs : 0) || t_dc != n_dc_tiles || t_pl != n_pl_tiles) return fail_arg("internal: table totals disagree");
+    }
   }
   auto t_seeds = tnow();
-  const size_t off_ts_dc = align_up(off_ts_lv + 4 * (size_t)tp_levels.back(), 256);
-  const size_t off_dictp = align_up(off_ts_dc + 4 * (size_t)tp_dict.back(), 256);
+  const size_t off_ts_dc = align_up(off_ts_lv + 4 * (size_t)n_lv_tiles, 256);
+  const size_t off_dictp = align_up(off_ts_dc + 4 * (size_t)n_dc_tiles, 256);
   const size_t upload_bytes = align_up(off_dictp + 4 * (size_t)n_dict, 256);
   const size_t off_state = upload_bytes;
   const size_t off_streams = align_up(off_state + sizeof(PageState) * (size_t)n_pages, 256);
   const size_t off_pgsum = align_up(off_streams + sizeof(Stream) * n_streams, 256);
-  const size_t meta_bytes = align_up(off_pgsum + 32 * (((size_t)n_pages + 255) / 256 + 1), 256);
+  const size_t off_tbsum = align_up(off_pgsum + 32 * (((size_t)n_pages + 255) / 256 + 1), 256);      // (sums of k_stream_table_sums)
+  const size_t meta_bytes = align_up(off_tbsum + (device_tables ? stream_tables_work_bytes(n_pages) : 0), 256);
 
   // a nullable column of PLAIN pages only: the scatter takes the values from the pages
   const bool plain_scatter = !levels_only && col->max_def > 0 && slots > 0 && any_plain && !any_dict_enc && !any_delta && !any_bss && !any_rle &&
@@ -523,7 +560,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
                              (col->physical_type == PQD_INT32 || col->physical_type == PQD_INT64 || col->physical_type == PQD_FLOAT ||
                               col->physical_type == PQD_DOUBLE) && h->opt[PQD_OPT_PLAIN_SCATTER] != 0;
   // ... and from the validity bits the level expansion leaves per tile, when every level stream goes through it
-  const int n_def_tiles = col->max_def > 0 ? tp_levels.back() - tp_levels[(size_t)nd] : 0;
+  const int n_def_tiles = col->max_def > 0 ? n_lv_tiles - n_lv_tiles_rep : 0;
   bool direct_rle = nd > 0 && data_bytes / nd <= 64 * 1024;      // small pages (the reference's writer cuts them at 8 KiB): try the RLE-only expansion first
   if (h->opt[PQD_OPT_DIRECT_RLE] >= 0) direct_rle = h->opt[PQD_OPT_DIRECT_RLE] == 1;
   const bool scatter_bits = plain_scatter && !direct_rle && n_def_tiles > 0 && h->opt[PQD_OPT_PLAIN_SCATTER] != 2;
@@ -539,7 +576,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
   if ((rc = h->runs.ensure(sizeof(RunEntry) * (size_t)(run_total + 64)))) return rc;
   if ((rc = h->tile_run.ensure(8 * (size_t)(tile_total + 64)))) return rc;
-  if ((rc = h->tile_desc.ensure(sizeof(TileDesc) * ((size_t)std::max(tp_levels.back(), tp_dict.back()) + 1)))) return rc;
+  if ((rc = h->tile_desc.ensure(sizeof(TileDesc) * ((size_t)std::max(n_lv_tiles, n_dc_tiles) + 1)))) return rc;
   const size_t val_bytes = (size_t)slots * (size_t)esz + 64;
   const bool nullable = col->max_def > 0;
   if (levels_only) {
@@ -605,13 +642,19 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (n_dict) std::memcpy(m + off_dictp, h->h_dict_pages.data(), 4 * (size_t)n_dict);
     // tile -> stream maps of the two hybrid expansions, written in place
     int32_t *ts_lv = reinterpret_cast<int32_t *>(m + off_ts_lv), *ts_dc = reinterpret_cast<int32_t *>(m + off_ts_dc);
-    for (size_t i = 0; i + 1 < tp_levels.size(); i++)
+    for (size_t i = 0; i + 1 < tp_levels.size() && !device_tables; i++)
       for (int32_t t = tp_levels[i]; t < tp_levels[i + 1]; t++) ts_lv[t] = (int32_t)i;
-    for (size_t i = 0; i + 1 < tp_dict.size(); i++)
+    for (size_t i = 0; i + 1 < tp_dict.size() && !device_tables; i++)
       for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
   }
   auto t_stage = tnow();
-  HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
+  if (device_tables) {      // the page table and the list of dictionary pages; the tables between them are the kernel's to write
+    uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
+    if (pages_bytes) HIP_TRY(hipMemcpyAsync(h->meta.p, m, pages_bytes, hipMemcpyHostToDevice, h->stream));
+    if (n_dict) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->meta.p) + off_dictp, m + off_dictp, 4 * (size_t)n_dict, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
+  }
   auto t_h2d = tnow();
 
   uint8_t *mb = static_cast<uint8_t *>(h->meta.p);
@@ -646,16 +689,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   const int w_lv = std::max(bit_len(col->max_def), bit_len(col->max_rep));
   const int stage_levels = kTile * w_lv / 8 + kTile / 4 + 64;
   int stage_dict = 18 * 1024;
-  if (!nullable) {
-    double bpv = 0.0;
-    for (int p = 0; p < n_pages; p++) {
-      const PageIn &pi = h->h_pages[(size_t)p];
-      if (pi.data_idx < 0 || !(is_dict_enc(pi.encoding) || pi.encoding == PQD_ENC_RLE)) continue;
-      if (pi.num_values >= kTile) bpv = std::max(bpv, (double)pi.body_len / (double)pi.num_values);
-      else bpv = std::max(bpv, 4.25);
-    }
-    stage_dict = (int)(bpv * kTile * 1.25) + 512;
-  }
+  if (!nullable) stage_dict = (int)(index_bpv * kTile * 1.25) + 512;      // (added up with the page table)
 
   // Few long streams: a workgroup per stream takes the decoding off the serial header walk.  Many short ones
   // (small pages): a wavefront per stream keeps more of them in flight.
@@ -670,9 +704,6 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   constexpr int kFusedMinLen = 16 * 1024;
   bool fused = nd > 0 && data_bytes / nd >= 2 * kFusedMinLen;
   if (h->opt[PQD_OPT_FUSED] >= 0) fused = h->opt[PQD_OPT_FUSED] == 1;
-  int max_dict_n = 0;
-  for (int p = 0; p < n_pages; p++)
-    if (h->h_pages[(size_t)p].data_idx < 0) max_dict_n = std::max(max_dict_n, h->h_pages[(size_t)p].dict_n);
 
   // hand-over of the dictionary expansion to the device's shared stream and back
   hipStream_t heavy = h->no_alloc ? nullptr : heavy_stream(h->device);
@@ -699,34 +730,28 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   // Expansion of the index streams: one launch per run of data pages that share a dictionary (the launch keeps its
   // dictionary in LDS where it fits); Encoding_RLE pages ride along with whatever launch covers their tiles.
   auto expand_dict_groups = [&](const ChunkCtx &cc, const uint8_t *table, int entry_size, uint8_t *out) -> int {
-    int p = 0;
-    while (p < n_pages) {
-      while (p < n_pages && h->h_pages[(size_t)p].data_idx < 0) p++;
-      if (p >= n_pages) break;
-      const int dict_of = h->h_pages[(size_t)p].dict_page;
-      const int d_lo = h->h_pages[(size_t)p].data_idx;
-      int d_hi = d_lo, q = p;
-      for (; q < n_pages; q++) {
-        const PageIn &pi = h->h_pages[(size_t)q];
-        if (pi.data_idx < 0) continue;
-        if (pi.dict_page != dict_of) break;
-        d_hi = pi.data_idx + 1;
-      }
-      const int t_lo = tp_dict[(size_t)d_lo], t_hi = tp_dict[(size_t)d_hi];
+    int64_t t_lo = 0;      // (index tiles are numbered in page order; the groups were found with the page table)
+    for (const pqd_handle::DictGroup &g : h->h_dict_groups) {
+      const int64_t t_hi = t_lo + g.tiles;
       if (t_hi > t_lo) {
-        const PageIn &dp = h->h_pages[(size_t)(dict_of >= 0 ? dict_of : p)];
-        const uint8_t *dptr = dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
-        const int dn = dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
-        HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, t_lo, t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
+        const PageIn &dp = h->h_pages[(size_t)(g.dict_of >= 0 ? g.dict_of : g.first_page)];
+        const uint8_t *dptr = g.dict_of >= 0 ? table + (size_t)dp.dict_off * (size_t)entry_size : table;
+        const int dn = g.dict_of >= 0 ? dp.dict_n : -1;   // -1: no dictionary in effect
+        HIP_TRY(launch_expand_dict(cc, d_tp_dc, d_ts_dc, (int)t_lo, (int)t_hi, stage_dict, dptr, dn, out, static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
                                    split_mode, heavy));
       }
-      p = q;
+      t_lo = t_hi;
     }
     return PQD_OK;
   };
 
   // ---- kernels ----
   if (n_pages > 0) {
+    if (device_tables) {
+      Prof pf(h, "k_stream_tables");
+      HIP_TRY(launch_stream_tables(c, tbases, mb + off_tbsum, reinterpret_cast<StreamSeed *>(mb + off_seeds), const_cast<int32_t *>(d_tp_lv), const_cast<int32_t *>(d_tp_dc),
+                                   const_cast<int32_t *>(d_tp_pl), const_cast<int32_t *>(d_ts_lv), const_cast<int32_t *>(d_ts_dc), h->stream));
+    }
     { Prof pf(h, "k_page_setup"); HIP_TRY(launch_page_setup(c, h->stream)); }
     if ((col->max_rep > 0 || col->max_def > 0) && nd > 0) {
       if (direct_rle) { Prof pf(h, "k_rle_only_pages(levels)"); HIP_TRY(launch_rle_only_levels(c, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), h->stream)); }
@@ -735,8 +760,8 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       int32_t *vcnt = scatter_bits ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(h->lvbits.p) + (size_t)n_def_tiles * (kTile / 8)) : nullptr;
       if (scatter_bits) HIP_TRY(hipMemsetAsync(vcnt, 0, 4 * (size_t)n_def_tiles, h->stream));
       { Prof pf(h, "k_hybrid_expand<levels>");
-        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, tp_levels.back(), stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
-                                     vbits, vcnt, tp_levels[(size_t)nd], h->stream)); }
+        HIP_TRY(launch_expand_levels(c, d_tp_lv, d_ts_lv, n_lv_tiles, stage_levels, static_cast<int32_t *>(h->rep.p), static_cast<int32_t *>(h->def.p), static_cast<TileDesc *>(h->tile_desc.p), h->n_cu,
+                                     vbits, vcnt, n_lv_tiles_rep, h->stream)); }
     }
   }
   { Prof pf(h, "k_pages_finalize"); HIP_TRY(launch_pages_finalize(c, d_totals, reinterpret_cast<int64_t *>(mb + off_pgsum), h->stream)); }
@@ -830,10 +855,10 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       HIP_TRY(from_heavy());
     }
     if (any_plain && !plain_scatter) {
-      if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
-      else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, tp_plain.back(), max_page_bytes, dense_out, h->stream)); }
+      if (col->physical_type == PQD_BOOLEAN) { Prof pf(h, "k_plain_boolean"); HIP_TRY(launch_plain_boolean(c, d_tp_pl, n_pl_tiles, dense_out, h->stream)); }
+      else { Prof pf(h, "k_plain_fixed"); HIP_TRY(launch_plain_fixed(c, d_tp_pl, n_pl_tiles, max_page_bytes, dense_out, h->stream)); }
     }
-    if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, tp_plain.back(), dense_out, h->stream)); }
+    if (any_bss) { Prof pf(h, "k_byte_stream_split"); HIP_TRY(launch_byte_stream_split(c, d_tp_pl, n_pl_tiles, dense_out, h->stream)); }
     if (any_delta) {
       // what the DELTA_BINARY_PACKED pages spend per value (levels included, which only makes the units smaller)
       int64_t db = 0, dv = 0;
@@ -872,7 +897,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     if (nullable && slots > 0) {
       Prof pf(h, scatter_bits ? "k_scatter(plain pages, validity bits)" : plain_scatter ? "k_scatter(plain pages)" : "k_scatter");
       if (scatter_bits)
-        HIP_TRY(launch_scatter_plain_bits(c, d_tp_lv, d_ts_lv, tp_levels[(size_t)nd], n_def_tiles, static_cast<const uint32_t *>(h->lvbits.p),
+        HIP_TRY(launch_scatter_plain_bits(c, d_tp_lv, d_ts_lv, n_lv_tiles_rep, n_def_tiles, static_cast<const uint32_t *>(h->lvbits.p),
                                           reinterpret_cast<const int32_t *>(static_cast<const uint8_t *>(h->lvbits.p) + (size_t)n_def_tiles * (kTile / 8)),
                                           static_cast<int64_t *>(h->scratch.p),
                                           static_cast<uint8_t *>(h->lvbits.p) + align_up((size_t)n_def_tiles * (kTile / 8 + 4) + 64, 256),

@@ -105,6 +105,19 @@ struct StreamSeed {
   int32_t tile_base;
 };
 
+// Where the three groups of streams (repetition levels, definition levels, values) start in the run table, the
+// tile -> run table and the level tile numbering, and which of them a call decodes: all the seeds of a call follow
+// from these and the page table.
+struct TableBases {
+  int64_t run_base[3];
+  int64_t tile_base[3];
+  int64_t tlv_base[2];
+  int32_t wanted[3];
+  int32_t rle_typed;   // Encoding_RLE value pages are index streams of this column (BOOLEAN, INT32, INT64)
+  int32_t is_real;     // FLOAT / DOUBLE: BYTE_STREAM_SPLIT pages count as plain tiles
+  int32_t pad;
+};
+
 // Run-table entry: x = out_start | (bit_packed << 31); y = RLE value, or byte offset of the packed
 // payload inside the stream; z = work items of all earlier runs of the stream, an item being up to eight
 // consecutive values of one run (a run of n values has ceil(n / 8) items; a bit-packed item is one group of

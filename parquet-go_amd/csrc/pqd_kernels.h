@@ -8,6 +8,11 @@ namespace pqd {
 
 // ---- k_hybrid.hip ----
 hipError_t launch_page_setup(const ChunkCtx &c, hipStream_t stream);
+// stream seeds, tile prefixes and tile -> stream maps from the uploaded page table (what the host otherwise writes and uploads)
+// (work: stream_tables_work_bytes(n_pages) bytes, 8-byte aligned)
+size_t stream_tables_work_bytes(int n_pages);
+hipError_t launch_stream_tables(const ChunkCtx &c, const TableBases &b, void *work, StreamSeed *seeds, int32_t *tp_levels, int32_t *tp_dict, int32_t *tp_plain,
+                                int32_t *ts_levels, int32_t *ts_dict, hipStream_t stream);
 // streams [s0, s0 + n): one wavefront walks the run headers of each stream
 // wide: one 576-thread workgroup per stream (few long streams) instead of one wavefront per stream
 // jump: the wavefront variant that also resolves spans of short runs at once (4 KiB more LDS per stream)

@@ -23,7 +23,7 @@ def dec(shared_dec):
     # one handle for the module (its work buffers are reused from test to test, as a reader reuses them from chunk
     # to chunk); kernel-variant choices a test pins are handed back to the library afterwards
     yield shared_dec
-    for opt in range(9):
+    for opt in range(10):
         shared_dec.set_option(opt, -1)
 
 
@@ -656,6 +656,48 @@ def test_levels_and_nulls(dec, oracle, max_def, max_rep, enc):
                             pg.level_block_v1(dl, max_def, rng, "arrow"))
     chunk, pages = cb.finish()
     check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
+
+
+@pytest.mark.parametrize("tables", [1, 0, -1])
+@pytest.mark.parametrize("shape", ["nested-mixed", "plain-nullable", "flat-dict", "rep-without-def"])
+def test_stream_tables_by_kernel_and_by_host(dec, oracle, shape, tables):
+    # The per-stream tables of a call (run-table ranges, tile prefixes, tile -> stream maps) come from a kernel for
+    # chunks of thousands of pages - what the reference's writer produces, 8 KiB a page (writer/writer.go:63-65) - and
+    # from the host otherwise: the same chunk both ways (and as the library chooses), with several dictionaries, pages
+    # of no values, pages of more than one tile, v1 and v2 pages and PLAIN / Encoding_RLE pages between the indexed ones.
+    dec.set_option(9, tables)                # PQD_OPT_DEVICE_TABLES
+    rng = np.random.default_rng(7700 + len(shape))
+    max_def, max_rep = {"nested-mixed": (3, 1), "plain-nullable": (1, 0), "flat-dict": (0, 0), "rep-without-def": (0, 2)}[shape]
+    cb = pg.ChunkBuilder(gap=int(rng.integers(0, 5)))
+    n_pages = 5000
+    sizes = rng.integers(1, 60, n_pages)
+    sizes[rng.integers(0, n_pages, 40)] = 0
+    sizes[rng.integers(0, n_pages, 6)] = rng.integers(4097, 15000, 6)
+    nd = 0
+    for k, n in enumerate(int(x) for x in sizes):
+        if shape != "plain-nullable" and (k % 1300 == 0 or (k == 2 and shape == "nested-mixed")):
+            nd = int(rng.integers(1, 400))
+            cb.dict_page(rng.integers(-2**62, 2**62, nd, dtype=np.int64).tobytes(), nd)
+        dl, rl = _levels(rng, n, max_def, max_rep) if n else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        nn = int((dl == max_def).sum()) if max_def else n
+        kind = "plain" if shape == "plain-nullable" else ("plain" if k % 17 == 5 else "delta" if k % 23 == 7 else "dict")
+        if kind == "plain":
+            body, e = rng.integers(-2**62, 2**62, nn, dtype=np.int64).tobytes(), pg.ENC_PLAIN
+        elif kind == "delta":
+            body, e = (pg.delta_encode_fast(np.cumsum(rng.integers(0, 1000, nn)).astype(np.int64)) if nn else b""), pg.ENC_DELTA_BINARY_PACKED
+        else:
+            body, e = pg.dict_indices_body(rng.integers(0, nd, nn), max(1, int(nd - 1).bit_length()), rng), pg.ENC_RLE_DICTIONARY
+        if nn == 0:
+            body = b""
+        if k % 3 == 1 and n:
+            cb.data_page_v2(e, n, body, pg.hybrid_encode(rl, int(max_rep).bit_length(), rng) if max_rep else b"",
+                            pg.hybrid_encode(dl, int(max_def).bit_length(), rng) if max_def else b"")
+        else:
+            cb.data_page_v1(e, n, body, pg.level_block_v1(rl, max_rep, rng) if max_rep else b"",
+                            pg.level_block_v1(dl, max_def, rng) if max_def else b"")
+    chunk, pages = cb.finish()
+    g, o = check_same(dec, oracle, chunk, pages, pg.INT64, 0, max_def, max_rep)
+    assert o.status == 0
 
 
 @pytest.mark.parametrize("how", ["bits", "levels", "levels-direct", "copy"])
