@@ -61,6 +61,7 @@ __global__ void k_page_setup(ChunkCtx c) {
     s.run_base = sd.run_base; s.run_cap = sd.run_cap; s.tile_base = sd.tile_base; s.pad = 0;
     s.off = 0; s.len = 0; s.avail = 0; s.w = 0; s.cnt = 0; s.out_base = pi.slot_base;
     s.page = p; s.n_runs = 0; s.status = 0; s.decoded = 0; s.direct = 0; s.spare = 0;
+    s.dict_off = 0; s.dict_n = 0; s.dict_ok = 0;
   }
   int64_t pos = pi.body_off, end = pi.body_off + pi.body_len;
   const int64_t nv = pi.num_values;
@@ -930,6 +931,7 @@ __global__ __launch_bounds__(256) void k_pages_values(ChunkCtx c, const int64_t 
   vs->cnt = 0;
   vs->status = ps->status;
   const bool dict_enc = pi.encoding == PQD_ENC_PLAIN_DICTIONARY || pi.encoding == PQD_ENC_RLE_DICTIONARY;
+  vs->dict_off = pi.dict_off; vs->dict_n = pi.dict_n; vs->dict_ok = dict_enc && pi.dict_page >= 0;
   if (ps->status == 0 && cnt > 0 && dict_enc) {
     const int64_t off = ps->val_off, len = ps->val_len;
     int st = 0;
@@ -979,7 +981,7 @@ constexpr int kDirectMaxLen = 64 * 1024;
 // layout/page.go:234-238); the values are the levels themselves, and the nulls (definition level below the maximum)
 // or row starts (repetition level 0) are counted into the page state as the tile expansion would.
 template <typename T, bool kLevels>
-__global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 8 : 6) void k_rle_only_pages(ChunkCtx c, const T *__restrict__ dict_table, T *__restrict__ values_out,
                                                         int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
   // One round takes 1536 runs, six consecutive runs per thread (a page of the reference's writer - 8 KiB, about 1400
   // runs - is one round).  The bytes of the stream come into LDS in 16-byte
@@ -989,7 +991,7 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   // the places - so that the stores are as wide and as dense as the output allows.  Nothing is checked ahead of time:
   // a header of another shape anywhere, or too few values, and the stream is left to the general path, which writes
   // the same places again.
-  constexpr int kWin = 8192;
+  constexpr int kWin = 7808;               // (bytes of a round and 15 of misalignment fit; with the other arrays eight workgroups of INT32 fit a CU's LDS)
   constexpr int kPer = 6;                  // runs per thread and round
   constexpr int kRound = 256 * kPer;
   __shared__ uint4 s_in4[kWin / 16 + 1];
@@ -1007,10 +1009,10 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
   int dict_n = 0;
   if (!kLevels) {
     // dictionary-encoded pages only, looked up in the dictionary in effect for the page
-    const PageIn &pg = c.pages[sp->page];
-    if ((pg.encoding != PQD_ENC_PLAIN_DICTIONARY && pg.encoding != PQD_ENC_RLE_DICTIONARY) || pg.dict_page < 0) return;
-    dict = dict_table + pg.dict_off;
-    dict_n = pg.dict_n;
+    // (what the page entry says about it was copied into the stream: one dependent load less before the bytes are asked for)
+    if (!sp->dict_ok) return;
+    dict = dict_table + sp->dict_off;
+    dict_n = sp->dict_n;
   }
   const uint32_t nb = (uint32_t)(w + 7) / 8, stride = 1u + nb;
   if ((uint32_t)len % stride) return;
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_rle_only_pages(ChunkCtx c, const T *__r
       win_runs = n_runs - k0 < fit ? n_runs - k0 : fit;      // (fit >= kRound: a round always fits)
       const uint32_t need = win_al + (uint32_t)win_runs * stride;
 #pragma unroll
-      for (int j = 0; j < kWin / 16 / 256; j++) {
+      for (int j = 0; j < (kWin / 16 + 255) / 256; j++) {
         const int ci = tid + 256 * j;
         if ((uint32_t)ci * 16u < need) {
           const uint8_t *q = r0 - win_al + 16 * ci;

@@ -96,6 +96,11 @@ struct Stream {
   int64_t decoded;   // values the whole stream holds (saturating)
   int32_t direct;    // the stream was expanded by k_rle_only_pages: no run table, no tiles
   int32_t spare;
+  // index streams of dictionary-encoded pages: the dictionary in effect, copied from the page entry so that a kernel
+  // that starts from the stream needs no second dependent load (k_pages_values)
+  int64_t dict_off;  // its first entry in the handle's dictionary table
+  int32_t dict_n;    // its entries
+  int32_t dict_ok;   // 1: the page is dictionary-encoded and a dictionary is in effect
 };
 
 // What the host knows about a stream before the page bodies are looked at; k_page_setup builds the Stream from it.

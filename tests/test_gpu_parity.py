@@ -145,6 +145,9 @@ def test_dict_parquet_go_style_width32_rle_only(dec, oracle):
         cb.data_page_v1(pg.ENC_PLAIN_DICTIONARY, n, bytes([32]) + oracle.write_rle_int32(idx.astype(np.int32), 32))
     chunk, pages = cb.finish()
     check_same(dec, oracle, chunk, pages, pg.INT32)
+    # every one of these pages (7 to 10 KiB of runs, more than one round of the kernel each) is expanded straight from
+    # the page; falling back to the general path would give the same values and hide a fault in the direct one
+    assert dec.direct_streams() == 40
 
 
 @pytest.mark.parametrize("direct", ["1", "0"])
