@@ -173,6 +173,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
   };
   // ---- stream header: four varints (at most 40 bytes, inside segment 0) ----
   uint64_t hdr[4];
+  bool overlong = false;      // a varint of more than ten bytes: the reference reads on and drops the bits beyond 64; such a stream is refused
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     uint64_t v = 0;
@@ -184,12 +185,14 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
       if (shift < 64) v |= (uint64_t)(b & 0x7Fu) << shift;
       if ((b & 0x80u) == 0) break;
       shift += 7;
+      if (n == 9) overlong = true;
     }
     hdr[i] = v;
   }
   const uint64_t block_size = hdr[0], n_mb = hdr[1], n_values = hdr[2];
   const T first = DeltaTraits<T>::zigzag(hdr[3]);
-  if (n_mb == 0) status = PQD_ERR_MALFORMED;                       // division by zero
+  if (overlong) status = PQD_ERR_REFUSED;
+  else if (n_mb == 0) status = PQD_ERR_MALFORMED;                  // division by zero
   else if (n_values > (1ull << 30)) status = PQD_ERR_MALFORMED;    // stands for the reference running out of memory
   else if (n_mb > 65535) status = PQD_ERR_MALFORMED;               // likewise (one uint64 per miniblock width)
   if (status != PQD_OK) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
         uint32_t d3 = __builtin_amdgcn_readfirstlane(ring[(di + 3) & (kRingDwords - 1)]);
         uint32_t d4 = __builtin_amdgcn_readfirstlane(ring[(di + 4) & (kRingDwords - 1)]);
         const uint64_t xhi = ((uint64_t)__builtin_amdgcn_alignbit(d4, d3, sh) << 32) | __builtin_amdgcn_alignbit(d3, d2, sh);
-        // minDelta varint (at most 10 bytes; a longer one is rejected)
+        // minDelta varint (at most 10 bytes; a longer one - the reference reads on and drops the bits beyond 64 - is refused)
         uint64_t md = 0;
         uint32_t hl = 0;
         {
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(64) void k_delta_decode(ChunkCtx c, T *values_out, 
             shift += 7;
           }
         }
-        if (hl >= 11) { status = PQD_ERR_MALFORMED; break; }
+        if (hl >= 11) { status = PQD_ERR_REFUSED; break; }
         min_delta = DeltaTraits<T>::zigzag(md);
         qp = q + hl;
         // the four width bytes: ReadByte at the end is io.EOF (encodingread.go:309-312)

@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 8 : 6) void k_rle_only_pages(
                                                         int32_t *__restrict__ rep_out, int32_t *__restrict__ def_out) {
   // One round takes 1536 runs, six consecutive runs per thread (a page of the reference's writer - 8 KiB, about 1400
   // runs - is one round).  The bytes of the stream come into LDS in 16-byte
-  // pieces, 8 KiB at a time (a page of the reference's writer fits whole); every thread parses its runs and asks for
+  // pieces, a window of 7808 bytes at a time (a round's bytes always fit it); every thread parses its runs and asks for
   // their dictionary entries together; a scan of the counts gives the runs their places, and the values go out by
   // position - four consecutive values per thread, the run that covers the first of them found by bisection over
   // the places - so that the stores are as wide and as dense as the output allows.  Nothing is checked ahead of time:

@@ -921,7 +921,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
     auto t_end = tnow();
     std::fprintf(stderr, "pqd host: pages %.1f us, seeds %.1f, ensure %.1f, staging %.1f, h2d call %.1f, launches %.1f (n_pages %d, upload %zu bytes)\n",
-                 us(t_begin, t_pages), us(t_pages, t_seeds), us(t_seeds, t_ensure), us(t_ensure, t_stage), us(t_stage, t_h2d), us(t_h2d, t_end), n_pages, upload_bytes);
+                 us(t_begin, t_pages), us(t_pages, t_seeds), us(t_seeds, t_ensure), us(t_ensure, t_stage), us(t_stage, t_h2d), us(t_h2d, t_end), n_pages, device_tables ? pages_bytes + 4 * (size_t)n_dict : upload_bytes);
   }
   return PQD_OK;
 }

@@ -620,6 +620,41 @@ def test_delta_reference_writer_and_other_geometries(dec, oracle):
     check_same(dec, oracle, chunk, pages, pg.INT64)
 
 
+@pytest.mark.parametrize("blocks", [-1, 0])
+@pytest.mark.parametrize("where", ["first value", "minimum delta"])
+def test_delta_varint_of_more_than_ten_bytes_is_refused(dec, oracle, where, blocks):
+    # ReadUnsignedVarInt (encodingread.go:127-143) reads on as long as the continuation bit is set and drops what is
+    # shifted beyond 64 bits: a varint padded with 0x80 bytes decodes to the same number there.  The library does not
+    # follow varints beyond ten bytes: it refuses the page (PQD_ERR_REFUSED, -13) and must not call it malformed -
+    # that would claim a panic the reference does not have.  The pages in front of it decode as usual.
+    dec.set_option(6, blocks)                # PQD_OPT_DELTA_BLOCKS
+    rng = np.random.default_rng(77)
+
+    def varint_end(b, i):
+        while b[i] & 0x80:
+            i += 1
+        return i + 1
+
+    vals = np.cumsum(rng.integers(-300, 300, 1000)).astype(np.int32)
+    good = pg.delta_encode(vals, np.int32)
+    i = 0
+    for _ in range(3 if where == "first value" else 4):
+        i = varint_end(good, i)
+    j = varint_end(good, i)
+    padded = bytearray(good[i:j])
+    padded[-1] |= 0x80
+    padded += b"\x80" * (12 - len(padded) - 1) + b"\x00"
+    bad = good[:i] + bytes(padded) + good[j:]
+    cb = pg.ChunkBuilder()
+    cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, len(vals), good)
+    cb.data_page_v1(pg.ENC_DELTA_BINARY_PACKED, len(vals), bad)
+    chunk, pages = cb.finish()
+    o = oracle.read_chunk(chunk, pages, pg.INT32, 0, 0, 0)
+    assert o.status == 0 and np.array_equal(np.ascontiguousarray(o.values).view(np.int32).ravel(), np.concatenate([vals, vals]))
+    g = dec.decode(chunk, pages, pg.INT32, 0, 0, 0)
+    assert g.status == -13 and g.bad_page == 1
+
+
 def _levels(rng, n, max_def, max_rep):
     dl = rng.integers(0, max_def + 1, n) if max_def else np.zeros(n, np.int64)
     # long stretches of equal levels, as real columns have
