@@ -369,6 +369,13 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   const size_t pages_bytes = sizeof(PageIn) * (size_t)n_pages;
   if ((rc = h->stage_meta.ensure(pages_bytes + 256))) return rc;
   h->h_pages = HostSpan<PageIn>{static_cast<PageIn *>(h->stage_meta.p), (size_t)n_pages};
+  // Chunks of very many pages: the page entries go to the device slice by slice while the host is still walking the
+  // rest, into the meta block as the call before left it.  Should that block or the staging block have to grow
+  // afterwards, the slices are uploaded again with everything else.
+  const int early_slice = h->opt[PQD_OPT_DEVICE_TABLES] == 1 ? 1024 : 4096;
+  void *const early_meta = (!h->no_alloc && !h->stage_meta.pageable && h->opt[PQD_OPT_POISON] <= 0 && h->opt[PQD_OPT_DEVICE_TABLES] != 0 &&
+                            n_pages >= 2 * early_slice && h->meta.p && h->meta.cap >= pages_bytes) ? h->meta.p : nullptr;
+  int early_done = 0;      // pages [0, early_done) are on their way
   h->h_dict_pages.clear();
   h->h_dict_groups.clear();
   double index_bpv = 0.0;      // most page bytes per value among the pages whose values are (or may be) an index stream
@@ -443,6 +450,11 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       } else {
         host_fail(PQD_ERR_UNSUPPORTED_PAGE_TYPE, p);   // INDEX_PAGE and unknown types, layout/page.go:813,934
       }
+      if (early_meta && p + 1 - early_done >= early_slice) {
+        HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(early_meta) + sizeof(PageIn) * (size_t)early_done, &h->h_pages[(size_t)early_done],
+                               sizeof(PageIn) * (size_t)(p + 1 - early_done), hipMemcpyHostToDevice, h->stream));
+        early_done = p + 1;
+      }
     }
   }
   auto t_pages = tnow();
@@ -458,6 +470,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
   const size_t off_tp_dc = align_up(off_tp_lv + 4 * (2 * (size_t)nd + 1), 256);
   const size_t off_tp_pl = align_up(off_tp_dc + 4 * ((size_t)nd + 1), 256);
   const size_t off_ts_lv = align_up(off_tp_pl + 4 * ((size_t)nd + 1), 256);
+  if (early_done && h->stage_meta.cap < off_ts_lv) HIP_TRY(hipStreamSynchronize(h->stream));      // (the slices on their way are read from the block that is about to move)
   if ((rc = h->stage_meta.ensure_keep(off_ts_lv, pages_bytes))) return rc;
   HostSpan<StreamSeed> h_seeds;
   HostSpan<int32_t> tp_levels, tp_dict, tp_plain;
@@ -571,6 +584,7 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
     for (DevBuf *b : h->all_bufs_) if (b->arena) { b->p = nullptr; b->cap = 0; }
     if (h->small.arena) h->small.arena->used = 0;
   }
+  if (early_done && h->stage_meta.cap < upload_bytes) HIP_TRY(hipStreamSynchronize(h->stream));
   if ((rc = h->meta.ensure(meta_bytes)) || (rc = h->stage_meta.ensure_keep(upload_bytes, off_ts_lv))) return rc;
   place_tables();
   if ((rc = h->small.ensure(256)) || (rc = h->host_small.ensure(256))) return rc;
@@ -648,12 +662,14 @@ int decode_on_device(pqd_handle *h, const uint8_t *base, size_t span, const pqd_
       for (int32_t t = tp_dict[i]; t < tp_dict[i + 1]; t++) ts_dc[t] = (int32_t)i;
   }
   auto t_stage = tnow();
+  // (page entries that went ahead and whose block is still where it was are not sent again)
+  const size_t sent = early_done && early_meta == h->meta.p ? sizeof(PageIn) * (size_t)early_done : 0;
   if (device_tables) {      // the page table and the list of dictionary pages; the tables between them are the kernel's to write
     uint8_t *m = static_cast<uint8_t *>(h->stage_meta.p);
-    if (pages_bytes) HIP_TRY(hipMemcpyAsync(h->meta.p, m, pages_bytes, hipMemcpyHostToDevice, h->stream));
+    if (pages_bytes > sent) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->meta.p) + sent, m + sent, pages_bytes - sent, hipMemcpyHostToDevice, h->stream));
     if (n_dict) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->meta.p) + off_dictp, m + off_dictp, 4 * (size_t)n_dict, hipMemcpyHostToDevice, h->stream));
   } else {
-    HIP_TRY(hipMemcpyAsync(h->meta.p, h->stage_meta.p, upload_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(h->meta.p) + sent, static_cast<uint8_t *>(h->stage_meta.p) + sent, upload_bytes - sent, hipMemcpyHostToDevice, h->stream));
   }
   auto t_h2d = tnow();
 
