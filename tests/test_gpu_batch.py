@@ -90,6 +90,24 @@ def test_many_chunks_of_a_column_in_one_call(dec, oracle, device_side):
     assert int(g.page_counts[:, 2].sum()) == o.n_slots
 
 
+@pytest.mark.parametrize("tables", [1, 0])
+def test_chunks_of_thousands_of_small_pages_in_one_call(dec, oracle, tables):
+    # row groups as the reference's writer cuts them - hundreds of pages of a few dozen values per chunk, a dictionary
+    # per chunk - with the per-stream tables of the call worked out by a kernel (and the page entries sent ahead in
+    # slices while the host walks the rest: from the second call on) or by the host
+    dec.set_option(9, tables)                # PQD_OPT_DEVICE_TABLES
+    try:
+        rng = np.random.default_rng(919)
+        parts = [int32_dict_chunk(rng, 700, 60, w, nd, lead=int(rng.integers(0, 9)), style=("rle" if k % 2 else "mixed"))
+                 for k, (w, nd) in enumerate([(3, 8), (12, 4096), (1, 2), (9, 300), (7, 100), (32, 500)])]
+        o = concat_oracle(oracle, parts, pg.INT32)
+        for _ in range(2):
+            dec.submit_chunks([c for c, _ in parts], [p for _, p in parts], pg.INT32)
+            same_table(dec.fetch(), o)
+    finally:
+        dec.set_option(9, -1)
+
+
 def test_many_small_nested_chunks_in_one_call(dec, oracle):
     # row groups of a nested column (optional list of optional int64: levels + PLAIN values), a few pages each
     from gen import pqgen
