@@ -216,7 +216,7 @@ def main():
 
     # ---- verification against the CPU oracle (untimed) + CPU baseline on a bounded sample ----
     cpu = None
-    if orc is not None:
+    if orc is not None and work:      # (no widths asked for: nothing to sample)
         cpu_vals, cpu_s, cpu_sn = 0, 0.0, 0.0
         for item in work:
             k = min(args.cpu_pages, len(item["pages"]) - 1)
